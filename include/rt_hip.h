@@ -1,0 +1,249 @@
+/*
+ * rt_hip.h — C ABI of the MI355X path-tracing hot path.
+ *
+ * This is the drop-in boundary for the reference renderer's per-pixel sample loop
+ * (reference: raytracer/src/main.rs:730-784 — the two pixel loops, minus write_color and the
+ * pixel store). Scene construction (main.rs:668-718), tone-map (main.rs:141-169) and image encode
+ * (main.rs:791-796) stay on the host side of this boundary.
+ *
+ * A scene crosses the boundary as the reference's own object graph, serialised into flat arrays:
+ * one RtHittable per `Arc<dyn Hittable>` (hittable.rs:51-60), one RtMaterial per
+ * `Arc<dyn Material>` (material.rs:11-21), one RtTexture per `Arc<dyn Texture>` (texture.rs:7-9).
+ * The library compiles that graph into its device layout (threaded BVH + per-type primitive
+ * arrays) at upload; the caller never sees device structures.
+ *
+ * Plain C: pointers and sizes only, no C++ or torch types. All geometry is f64 at the boundary
+ * (the reference is f64 throughout, vec3.rs:5-8); the device path computes in f32.
+ *
+ * Error convention: every entry point returns 0 on success or a negative RtStatus; a message is
+ * available from rt_last_error(). Nothing aborts and no C++ exception crosses the boundary
+ * (the reference panics instead: main.rs:656,762,777,779).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+typedef enum RtStatus {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* bad argument / malformed scene graph */
+    RT_ERR_UNSUPPORTED = -2,  /* graph shape the device compiler does not handle */
+    RT_ERR_DEVICE = -3,       /* HIP runtime error (message has hipGetErrorString) */
+    RT_ERR_NO_DEVICE = -4,    /* no usable GPU: the product path has no CPU fallback */
+    RT_ERR_OOM = -5
+} RtStatus;
+
+/* vec3.rs:5-8 */
+typedef struct RtVec3 { double x, y, z; } RtVec3;
+
+/* camera.rs:6-18, field for field. Filled by the host-side Camera::new (camera.rs:21-59). */
+typedef struct RtCamera {
+    RtVec3 origin;
+    RtVec3 lower_left_corner;
+    RtVec3 horizontal;
+    RtVec3 vertical;
+    RtVec3 u, v, w;
+    double lens_radius;
+    double time0, time1;
+} RtCamera;
+
+/* texture.rs */
+typedef enum RtTextureKind {
+    RT_TEX_SOLID = 0,    /* texture.rs:12-38  */
+    RT_TEX_CHECKER = 1,  /* texture.rs:41-69  */
+    RT_TEX_NOISE = 2,    /* texture.rs:72-96  */
+    RT_TEX_IMAGE = 3     /* texture.rs:99-140 */
+} RtTextureKind;
+
+typedef struct RtTexture {
+    int32_t kind;
+    int32_t a;      /* checker: `even` texture id; noise: perlin id; image: image id (-1 = empty) */
+    int32_t b;      /* checker: `odd` texture id */
+    int32_t _pad;
+    RtVec3 color;   /* solid: color_value */
+    double scale;   /* noise: scale */
+} RtTexture;
+
+/* perlin.rs:7-12 — tables are built on the host (perlin.rs:14-25,53-66) */
+typedef struct RtPerlin {
+    double ranvec[256][3];
+    uint32_t perm_x[256];
+    uint32_t perm_y[256];
+    uint32_t perm_z[256];
+} RtPerlin;
+
+/* texture.rs:99-104 — RGB8, row-major, bytes_per_scanline = 3*width */
+typedef struct RtImage {
+    const uint8_t* data;
+    uint32_t width;
+    uint32_t height;
+} RtImage;
+
+/* material.rs */
+typedef enum RtMaterialKind {
+    RT_MAT_LAMBERTIAN = 0,     /* material.rs:23-72   */
+    RT_MAT_METAL = 1,          /* material.rs:74-108  */
+    RT_MAT_DIELECTRIC = 2,     /* material.rs:110-156 */
+    RT_MAT_DIFFUSE_LIGHT = 3,  /* material.rs:158-191 */
+    RT_MAT_ISOTROPIC = 4       /* material.rs:193-220 (commented out in the reference: spec only) */
+} RtMaterialKind;
+
+typedef struct RtMaterial {
+    int32_t kind;
+    int32_t texture;  /* lambertian albedo / diffuse-light emit / isotropic albedo: texture id */
+    RtVec3 albedo;    /* metal */
+    double fuzz;      /* metal; the constructor clamps to <= 1 (material.rs:90) */
+    double ir;        /* dielectric */
+} RtMaterial;
+
+/* One record per `Arc<dyn Hittable>` of the reference graph. */
+typedef enum RtHittableKind {
+    RT_HIT_SPHERE = 0,          /* sphere.rs:11-24         p = center[3], radius                     */
+    RT_HIT_MOVING_SPHERE = 1,   /* moving_sphere.rs:8-34   p = center0[3], center1[3], time0, time1, radius */
+    RT_HIT_XY_RECT = 2,         /* aarect.rs:10-29         p = x0, x1, y0, y1, k                      */
+    RT_HIT_XZ_RECT = 3,         /* aarect.rs:60-79         p = x0, x1, z0, z1, k                      */
+    RT_HIT_YZ_RECT = 4,         /* aarect.rs:129-148       p = y0, y1, z0, z1, k                      */
+    RT_HIT_TRIANGLE = 5,        /* not in the reference (README.md:151-153): p = v0[3], v1[3], v2[3]  */
+    RT_HIT_BOX = 6,             /* boxes.rs:11-75          p = p0[3], p1[3]  (six rects, boxes.rs order) */
+    RT_HIT_LIST = 7,            /* hittable_list.rs:11-36  children                                   */
+    RT_HIT_BVH = 8,             /* bvh.rs:10-14,74         children, p = time0, time1                 */
+    RT_HIT_TRANSLATE = 9,       /* hittable.rs:62-74       first_child = child id, p = offset[3]      */
+    RT_HIT_ROTATE_Y = 10,       /* hittable.rs:98-145      first_child = child id, p = angle (degrees) */
+    RT_HIT_FLIP_FACE = 11,      /* hittable.rs:183-193     first_child = child id                     */
+    RT_HIT_CONSTANT_MEDIUM = 12 /* constant_medium.rs:9-29 (commented spec) first_child = boundary id,
+                                   material = phase function (isotropic), p = density                 */
+} RtHittableKind;
+
+typedef struct RtHittable {
+    int32_t kind;
+    int32_t material;      /* material id for primitives, boxes and media; -1 otherwise */
+    int32_t first_child;   /* LIST/BVH: offset into children[]; wrappers/medium: child hittable id */
+    int32_t n_children;    /* LIST/BVH: number of children; wrappers/medium: 1; primitives: 0 */
+    double p[10];
+} RtHittable;
+
+typedef enum RtBackgroundMode {
+    RT_BG_CONSTANT = 0,     /* main.rs:692 `background` colour returned on a miss (main.rs:74-76) */
+    RT_BG_SKY_GRADIENT = 1  /* book-1 sky: (1-t)*white + t*background, t = 0.5*(unit(d).y + 1);
+                               not in the reference (it only has the constant colour) */
+} RtBackgroundMode;
+
+typedef struct RtSceneDesc {
+    uint32_t abi_version;   /* RT_ABI_VERSION */
+    uint32_t _pad0;
+    const RtHittable* hittables;  uint64_t n_hittables;
+    const int32_t*    children;   uint64_t n_children;
+    const RtMaterial* materials;  uint64_t n_materials;
+    const RtTexture*  textures;   uint64_t n_textures;
+    const RtPerlin*   perlins;    uint64_t n_perlins;
+    const RtImage*    images;     uint64_t n_images;
+    int32_t world;            /* root hittable id (main.rs:668 `world`) */
+    int32_t lights;           /* root of the lights list (main.rs:669-686) or -1: no lights, the
+                                 integrator then samples CosinePdf only (book-1/2 behaviour) */
+    int32_t background_mode;  /* RtBackgroundMode */
+    int32_t _pad1;
+    RtVec3 background;        /* constant colour, or the sky gradient's far colour (0.5,0.7,1.0) */
+    uint64_t bvh_seed;        /* seeds the per-node axis draw of BVHNode::construct (bvh.rs:87) */
+} RtSceneDesc;
+
+typedef enum RtNanPolicy {
+    RT_NAN_PER_SAMPLE = 0,  /* a non-finite sample contributes 0 (documented deviation) */
+    RT_NAN_REFERENCE = 1    /* samples are summed as they are; write_color scrubs the pixel SUM
+                               (main.rs:146-155): one NaN sample blacks the pixel */
+} RtNanPolicy;
+
+enum {
+    RT_FLAG_COUNTERS = 1u,  /* count AABB tests and primitive tests on the device (slower) */
+    RT_FLAG_TIMING = 2u     /* bracket every kernel launch with HIP events (RtStats *_ms) */
+};
+
+typedef struct RtParams {
+    uint32_t width, height;       /* main.rs:660-661 */
+    uint32_t samples_per_pixel;   /* main.rs:662 */
+    uint32_t max_depth;           /* main.rs:663 */
+    uint64_t seed;                /* render seed: output is a pure function of (scene, camera, params) */
+    uint32_t nan_policy;          /* RtNanPolicy */
+    uint32_t flags;               /* RT_FLAG_* */
+    /* framebuffer sharding (one process per GPU): the image is cut into tile_size x tile_size
+       tiles, numbered row-major; this call renders tiles t with t % shard_count == shard_index.
+       shard_count <= 1 renders the whole image. */
+    uint32_t tile_size;           /* 0 = default (32) */
+    uint32_t shard_index;
+    uint32_t shard_count;
+    uint32_t pool_slots;          /* paths in flight; 0 = library default */
+} RtParams;
+
+#define RT_N_PRIM_TYPES 6  /* sphere, moving sphere, rect, triangle, medium, instance transform */
+
+typedef struct RtStats {
+    double render_ms;         /* first launch to framebuffer resident at the destination */
+    double extend_ms;         /* sum of traversal-kernel durations (HIP events; RT_FLAG_TIMING) */
+    double shade_ms;          /* sum of shade-kernel durations */
+    double other_ms;          /* generate / resolve kernels */
+    uint64_t samples;         /* camera paths traced */
+    uint64_t segments;        /* ray segments traced (world.hit calls, main.rs:74) */
+    uint64_t node_tests;      /* Aabb::hit evaluations (RT_FLAG_COUNTERS) */
+    uint64_t prim_tests[RT_N_PRIM_TYPES];
+    uint32_t iterations;      /* wavefront iterations */
+    uint32_t extend_launches;
+    uint32_t shade_launches;
+    uint32_t pool_slots;
+    uint64_t scene_nodes;     /* threaded-BVH nodes on the device */
+    uint64_t scene_prims;
+    uint64_t scene_bytes;     /* device bytes of nodes + primitives */
+    uint32_t bvh_in_lds;      /* 1 if the whole node/primitive set is staged in LDS */
+    uint32_t _pad;
+} RtStats;
+
+typedef struct RtCtx RtCtx;      /* one per (process, device, stream); not re-entrant */
+typedef struct RtScene RtScene;  /* device-resident compiled scene, owned by the library */
+
+/* Create a context on `device_id`. `stream` is a hipStream_t to launch on (so a caller such as
+   PyTorch can order the work with its own), or NULL for a stream owned by the library. */
+int rt_ctx_create(int device_id, void* stream, RtCtx** out_ctx);
+int rt_ctx_destroy(RtCtx* ctx);
+
+/* Compile the graph and copy it to the device. The caller keeps ownership of every pointer in
+   `desc`; nothing in it is retained after the call returns. */
+int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene);
+int rt_scene_destroy(RtCtx* ctx, RtScene* scene);
+
+/* Number of floats rt_render writes: 3 * pixels covered by this shard's tiles. For
+   shard_count <= 1 this is 3*width*height. */
+int rt_output_floats(const RtParams* params, uint64_t* out_n);
+
+/* Replaces the body of the pixel loops main.rs:731-784 (without write_color). Writes per-pixel
+   RGB *sums* over the samples (what main.rs:772 accumulates), f32:
+     - shard_count <= 1: rgb_sum[(y*width + x)*3 + c], row 0 = top of the image, i.e. the
+       reference's j = height-1-y (main.rs:733);
+     - sharded: this shard's tiles back to back, each tile_size*tile_size*3 floats row-major
+       (pixels outside the image are 0); rt_untile() on the host puts gathered shards in place.
+   rt_render copies to a host buffer; rt_render_device leaves the result in device memory the
+   caller owns (e.g. a torch tensor that RCCL then gathers). Both block until done. */
+int rt_render(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* params,
+              float* rgb_sum_host, RtStats* stats);
+int rt_render_device(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* params,
+                     void* rgb_sum_device, RtStats* stats);
+
+/* Host-side helper: scatter `shard_count` gathered shard buffers (each rt_output_floats long,
+   in shard order) into a full-frame rgb_sum. */
+int rt_untile(const RtParams* params, const float* gathered, float* rgb_sum);
+
+/* write_color (main.rs:141-169) on the device: rgb_sum (device, full frame) -> RGB8 (device). */
+int rt_resolve_device(RtCtx* ctx, const void* rgb_sum_device, uint32_t width, uint32_t height,
+                      uint32_t samples_per_pixel, void* rgb8_device);
+
+const char* rt_last_error(const RtCtx* ctx);  /* ctx may be NULL: last error of this thread */
+uint32_t rt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,183 @@
+"""Thin object wrappers over librt_hip.so. Names follow the C ABI (include/rt_hip.h, include/rt_host.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi as A
+from .build import LIB_PATH
+
+_lib = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rt error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return LIB_PATH
+
+
+def lib():
+    """Load librt_hip.so. Raises if it has not been built (python __graft_entry__.py / build.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtError(A.RT_ERR_NO_DEVICE, f"{LIB_PATH} is missing: build it first (ray-tracer-archive_amd/build.py); "
+                          "the product path has no fallback")
+        _lib = A.declare(C.CDLL(LIB_PATH))
+        if _lib.rt_abi_version() != A.RT_ABI_VERSION:
+            raise RtError(A.RT_ERR_INVALID, "librt_hip.so ABI version mismatch")
+    return _lib
+
+
+def _check(code, ctx=None):
+    if code != A.RT_OK:
+        msg = lib().rt_last_error(ctx).decode() if ctx is not None else lib().rt_last_error(None).decode()
+        raise RtError(code, msg)
+
+
+def make_params(width, height, spp, max_depth=50, seed=1, nan_policy=A.RT_NAN_PER_SAMPLE, flags=0, tile_size=0, shard_index=0,
+                shard_count=1, pool_slots=0):
+    return A.RtParams(width, height, spp, max_depth, seed, nan_policy, flags, tile_size, shard_index, shard_count, pool_slots)
+
+
+def output_floats(params):
+    n = C.c_uint64(0)
+    _check(lib().rt_output_floats(C.byref(params), C.byref(n)))
+    return n.value
+
+
+def _vec(v):
+    return (C.c_double * len(v))(*[float(x) for x in v])
+
+
+def camera_new(lookfrom, lookat, vup, vfov, aspect_ratio, aperture, focus_dist, time0, time1):
+    """Camera::new (camera.rs:21-59)."""
+    cam = A.RtCamera()
+    lib().rt_host_camera_new(_vec(lookfrom), _vec(lookat), _vec(vup), _vec([vfov, aspect_ratio, aperture, focus_dist]), time0, time1, C.byref(cam))
+    return cam
+
+
+def write_color(pixel_color, spp):
+    """write_color (main.rs:141-169) for one pixel sum."""
+    out = (C.c_uint8 * 3)()
+    lib().rt_host_write_color(_vec(pixel_color), spp, out)
+    return tuple(out)
+
+
+def tonemap(rgb_sum, spp):
+    rgb_sum = np.ascontiguousarray(rgb_sum, dtype=np.float32)
+    h, w, _ = rgb_sum.shape
+    out = np.empty((h, w, 3), dtype=np.uint8)
+    _check(lib().rt_host_tonemap(rgb_sum.ctypes.data_as(C.POINTER(C.c_float)), w, h, spp, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out
+
+
+def write_png(path, rgb8):
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = rgb8.shape
+    return lib().rt_host_write_png(str(path).encode(), rgb8.ctypes.data_as(C.POINTER(C.c_uint8)), w, h)
+
+
+def untile(params, gathered):
+    gathered = np.ascontiguousarray(gathered, dtype=np.float32)
+    out = np.zeros((params.height, params.width, 3), dtype=np.float32)
+    _check(lib().rt_untile(C.byref(params), gathered.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+class HostScene:
+    """A scene function of main.rs, built by the C++ host mirror (host/rt_host.hpp)."""
+
+    def __init__(self, name, scene_seed=1, arg0=0, arg1=0, image=None):
+        self._h = C.c_void_p()
+        self._image = None
+        ip, iw, ih = None, 0, 0
+        if image is not None:
+            self._image = np.ascontiguousarray(image, dtype=np.uint8)
+            ih, iw, _ = self._image.shape
+            ip = self._image.ctypes.data_as(C.POINTER(C.c_uint8))
+        _check(lib().rt_host_scene_create(name.encode(), scene_seed, arg0, arg1, ip, iw, ih, C.byref(self._h)))
+        self.name = name
+
+    @property
+    def desc(self):
+        return lib().rt_host_scene_desc(self._h).contents
+
+    def camera(self, aspect_ratio):
+        cam = A.RtCamera()
+        _check(lib().rt_host_scene_camera(self._h, float(aspect_ratio), C.byref(cam)))
+        return cam
+
+    def close(self):
+        if self._h:
+            lib().rt_host_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scene:
+    def __init__(self, ctx, desc):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        _check(lib().rt_scene_upload(ctx._h, C.byref(desc), C.byref(self._h)), ctx._h)
+
+    def close(self):
+        if self._h and self.ctx._h:
+            lib().rt_scene_destroy(self.ctx._h, self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """rt_ctx_create: one per (process, device, stream)."""
+
+    def __init__(self, device_id=0, stream=None):
+        self._h = C.c_void_p()
+        _check(lib().rt_ctx_create(device_id, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+
+    def upload(self, desc):
+        return Scene(self, desc)
+
+    def render(self, scene, cam, params):
+        """rt_render: returns (rgb_sum float32 array, stats dict). Full frame -> (H, W, 3); sharded -> flat."""
+        n = output_floats(params)
+        out = np.empty(n, dtype=np.float32)
+        st = A.RtStats()
+        _check(lib().rt_render(self._h, scene._h, C.byref(cam), C.byref(params), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)), self._h)
+        if params.shard_count <= 1:
+            out = out.reshape(params.height, params.width, 3)
+        return out, st.as_dict()
+
+    def render_device(self, scene, cam, params, device_ptr):
+        """rt_render_device: result stays in caller-owned device memory (e.g. a torch tensor's data_ptr())."""
+        st = A.RtStats()
+        _check(lib().rt_render_device(self._h, scene._h, C.byref(cam), C.byref(params), C.c_void_p(device_ptr), C.byref(st)), self._h)
+        return st.as_dict()
+
+    def resolve_device(self, rgb_sum_ptr, width, height, spp, rgb8_ptr):
+        _check(lib().rt_resolve_device(self._h, C.c_void_p(rgb_sum_ptr), width, height, spp, C.c_void_p(rgb8_ptr)), self._h)
+
+    def close(self):
+        if self._h:
+            lib().rt_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,39 @@
+"""Builds librt_hip.so (HIP kernels + C ABI + host mirror) for gfx950 with hipcc, in-tree."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "librt_hip.so")
+SOURCES = ["csrc/kernels.hip", "csrc/rt_api.cpp", "csrc/scene_compile.cpp", "host/host_capi.cpp"]
+HEADERS = ["csrc/kernels.h", "csrc/device_types.h", "csrc/scene_compile.hpp", "host/rt_host.hpp", "../include/rt_hip.h", "../include/rt_host.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source of the package for gfx950. Raises on failure."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build the HIP library")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc] + FLAGS + ["-o", LIB_PATH] + SOURCES + ["-lz"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

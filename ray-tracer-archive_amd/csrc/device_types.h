@@ -1,0 +1,88 @@
+// device_types.h — layout of a compiled scene in HBM (and, when it fits, in LDS).
+// Shared by the host-side scene compiler (scene_compile.cpp) and the HIP kernels (kernels.hip).
+#pragma once
+#include <stdint.h>
+
+namespace rtd {
+
+// ---- threaded BVH -------------------------------------------------------------------------------
+// One 32-byte record per node, laid out in depth-first pre-order = the order BVHNode::hit
+// (bvh.rs:134-143) and HittableList::hit (hittable_list.rs:39-51) visit things: left before right,
+// list members in insertion order. Traversal needs no stack:
+//     box test passes (or the node has no box)  -> run the node's leaf payload, go to i+1
+//     box test fails                            -> go to `skip` (first node after this subtree)
+// A node is two float4: (mn.xyz, skip) and (mx.xyz, leaf).
+struct Node {
+    float mn[3];
+    uint32_t skip;
+    float mx[3];
+    uint32_t leaf;   // 0: inner node. else (type << 28) | (count << 24) | first
+};
+static_assert(sizeof(Node) == 32, "node record is 32 bytes");
+
+enum LeafType : uint32_t {
+    LT_NONE = 0,
+    LT_SPHERE = 1,   // first/count index spheres[]
+    LT_MOVING = 2,   // moving[]
+    LT_RECT = 3,     // rects[]
+    LT_TRI = 4,      // tris[]
+    LT_MEDIUM = 5,   // media[]
+    LT_ENTER = 6,    // first = xform id: current ray := xform(world ray)      (Translate/RotateY::hit)
+    LT_EXIT = 7      // first = xform id to restore (0 = world ray)
+};
+constexpr uint32_t LEAF_MAX_COUNT = 15;
+constexpr uint32_t LEAF_MAX_FIRST = (1u << 24) - 1;
+inline uint32_t make_leaf(uint32_t type, uint32_t first, uint32_t count) { return (type << 28) | (count << 24) | first; }
+
+// A node without a box (list members, wrappers) stores mn.x = -inf: the slab test passes and the
+// node is not counted as an Aabb::hit.
+
+// ---- primitives: one geometry array per type (16-byte records) + one u32 `meta` per primitive ----
+// meta = material id (22 bits) | ff_mode << 22 | xform id << 24
+// ff_mode: what the wrappers above the primitive do to HitRecord::front_face (hittable.rs:82-83,
+// 173, 199): 0 keep, 1 negate (FlipFace), 2 force true (Translate/RotateY), 3 force false.
+constexpr uint32_t META_MAT_MASK = (1u << 22) - 1;
+inline uint32_t make_meta(uint32_t mat, uint32_t ff_mode, uint32_t xform) { return (mat & META_MAT_MASK) | (ff_mode << 22) | (xform << 24); }
+
+struct Float4 { float x, y, z, w; };
+// sphere   : 1 x Float4  (center.xyz, radius)                                   sphere.rs:11-15
+// moving   : 3 x Float4  (center0.xyz, radius) (center1.xyz, time0) (time1,0,0,0)  moving_sphere.rs:8-15
+// rect     : 2 x Float4  (a0, a1, b0, b1) (k, kaxis as float 0/1/2, 0, 0)        aarect.rs:10-17 (kaxis 2=Xy,1=Xz,0=Yz)
+// triangle : 3 x Float4  (v0,0) (v1,0) (v2,0)
+
+// hit record prim id: (leaf type << 28) | index into that type's array; 0 = miss
+constexpr uint32_t HIT_NONE = 0;
+
+// ---- transforms ----------------------------------------------------------------------------------
+// A chain of Translate / RotateY wrappers composed into: local = RotY(-theta)(world - offset).
+struct Xform { float sin_t, cos_t, off[3]; float _pad[3]; };   // 32 B; id 0 = identity
+
+// ---- media (constant_medium.rs) --------------------------------------------------------------------
+struct Medium {
+    uint32_t boundary_type;   // LT_SPHERE or LT_RECT (a Box: six consecutive rects)
+    uint32_t boundary_first;
+    uint32_t boundary_count;
+    uint32_t boundary_xform;  // xform applied to the ray before the boundary test (0 = none)
+    float neg_inv_density;
+    uint32_t meta;            // phase-function material etc.
+    uint32_t medium_id;       // key of the free-path draw (= hittable id in the scene graph)
+    uint32_t _pad;
+};
+
+// ---- materials / textures ----------------------------------------------------------------------------
+enum MatKind : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_DIFFUSE_LIGHT = 3, MK_ISOTROPIC = 4 };
+constexpr uint32_t TEX_INLINE = 0xFFFFFu;   // solid colour folded into the material record
+// mat_a[i] = (colour.rgb, param) with colour = solid albedo / emit colour, param = fuzz or ir
+// mat_b[i] = kind | (texture id << 4)         texture id TEX_INLINE: use mat_a colour
+inline uint32_t make_mat_b(uint32_t kind, uint32_t tex) { return kind | (tex << 4); }
+
+enum TexKind : uint32_t { TK_SOLID = 0, TK_CHECKER = 1, TK_NOISE = 2, TK_IMAGE = 3 };
+struct Texture { uint32_t kind; int32_t a, b; float scale; float color[3]; uint32_t _pad; };   // 32 B
+struct PerlinTable { Float4 ranvec[256]; uint32_t perm_x[256], perm_y[256], perm_z[256]; };
+struct Image { uint64_t offset; uint32_t width, height; };   // offset into the image byte pool
+
+// ---- lights (main.rs:669-686; only XzRect and Sphere implement pdf_value/random) ---------------------
+enum LightKind : uint32_t { LK_DEFAULT = 0, LK_XZRECT = 1, LK_SPHERE = 2 };
+struct Light { uint32_t kind; float p[5]; uint32_t _pad[2]; };   // rect: a0,a1,b0,b1,k   sphere: c.xyz, r
+
+}  // namespace rtd

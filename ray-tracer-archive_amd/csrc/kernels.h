@@ -1,0 +1,74 @@
+// kernels.h — kernel argument blocks and launch entry points (kernels.hip <-> rt_api.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+
+namespace rtk {
+
+// features a scene needs beyond "static spheres + Lambertian/Metal/Dielectric + BVH"
+enum : uint32_t {
+    F_MOVING = 1u, F_RECT = 2u, F_TRI = 4u, F_MEDIUM = 8u, F_XFORM = 16u, F_TEX = 32u, F_LIGHTS = 64u,
+    F_ALL = 127u
+};
+#define RT_N_PRIM_TYPES_K 6
+enum : uint32_t { CTR_NODE_TESTS = 0, CTR_PRIM_TESTS = 1, CTR_SAMPLES = 7, CTR_COUNT = 8 };
+#define RT_BG_SKY_GRADIENT_K 1
+#define RT_NAN_PER_SAMPLE_K 0u
+
+struct SceneDev {
+    const rtd::Float4* nodes; uint32_t n_nodes;
+    const rtd::Float4* spheres; const uint32_t* sphere_meta; uint32_t n_spheres;
+    const rtd::Float4* moving; const uint32_t* moving_meta;
+    const rtd::Float4* rects; const uint32_t* rect_meta;
+    const rtd::Float4* tris; const uint32_t* tri_meta;
+    const rtd::Medium* media;
+    const rtd::Xform* xforms;
+    const rtd::Float4* mat_a; const uint32_t* mat_b;
+    const rtd::Texture* textures;
+    const rtd::PerlinTable* perlins;
+    const rtd::Image* images; const uint8_t* image_bytes;
+    const rtd::Light* lights; uint32_t n_lights;
+};
+
+// Path pool: structure of arrays, one 16-byte lane-contiguous record per array and slot.
+//   ray_o = (origin.xyz, time)         ray_d = (direction.xyz, -)         hit = (t, primitive id)
+//   s0 = (T.rgb, L.r)  s1 = (L.gb, acc.rg)  s2 = (acc.b, work, sample_in_block<<8|depth, rng.lo)
+//   s3 = (rng.hi, base.lo, base.hi, -)
+struct PoolDev {
+    rtd::Float4* ray_o; rtd::Float4* ray_d; uint2* hit;
+    rtd::Float4* s0; rtd::Float4* s1; rtd::Float4* s2; rtd::Float4* s3;
+};
+
+struct RenderDev {
+    // camera.rs:6-18 in f32
+    float cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
+    float cam_lens_radius, cam_time0, cam_time1;
+    uint32_t width, height, spp, max_depth;
+    uint64_t seed;
+    uint32_t nan_policy;
+    int32_t bg_mode; float bg[3];
+    // framebuffer tiling / work decomposition
+    uint32_t tile_size, tiles_x, tiles_y, shard_index, shard_count;
+    uint32_t block_len;     // samples per work item
+    uint32_t n_blocks;      // work items per pixel = ceil(spp / block_len)
+    uint32_t total_items;   // n_local_tiles * n_blocks * tile_size^2
+    rtd::Float4* blocksum;  // [total_items]: RGB sum of one work item's samples
+};
+
+struct LaunchCfg {
+    uint32_t extend_blocks;   // persistent grid
+    uint32_t features;        // F_* the scene needs
+    bool scene_in_lds;
+};
+
+hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_init, uint32_t* next_work, uint32_t* out_count, hipStream_t stream);
+hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
+                         uint32_t* head, unsigned long long* counters, bool count, hipStream_t stream);
+hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
+                        const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, unsigned long long* counters, bool count, hipStream_t stream);
+hipError_t launch_resolve(const RenderDev& rd, float* out, uint32_t n_local_tiles, hipStream_t stream);
+hipError_t launch_write_color(const float* rgb_sum, uint32_t n_pixels, uint32_t spp, uint8_t* rgb8, hipStream_t stream);
+
+}  // namespace rtk

@@ -1,0 +1,907 @@
+// kernels.hip — the path-tracing hot path for gfx950 (MI355X, CDNA4), hand-written HIP.
+//
+// Wavefront formulation of the reference's per-sample loop (main.rs:751-763) and ray_color
+// recursion (main.rs:63-139):
+//
+//   k_generate : fills the path pool — each slot takes a work item (pixel, block of samples) and
+//                builds its first camera ray (Camera::get_ray, camera.rs:60-70).
+//   k_extend   : world.hit (main.rs:74) for every ray in the pool. Persistent waves pull rays from
+//                the SoA queue in HBM; a lane that finishes its ray refills from the wave's chunk
+//                (wave64 __ballot + mbcnt prefix), so lanes stay busy although rays need very
+//                different numbers of node visits. Traversal is a stackless walk of the threaded
+//                BVH (device_types.h) in the reference's order (bvh.rs:134-143); nodes and sphere
+//                records are staged in LDS when they fit.
+//   k_shade    : everything after world.hit for one segment: emitted / scatter / pdf sampling
+//                (main.rs:78-138), throughput update, next ray; finished samples accumulate into
+//                the slot's block sum and the slot regenerates a camera ray for its next sample or
+//                draws a new work item. Survivors are written to the other pool densely
+//                (__ballot/popc compaction).
+//   k_resolve  : sums each pixel's block sums in block order (deterministic, no float atomics).
+//
+// No MFMA: there is no dense contraction on this path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+#include "kernels.h"
+
+namespace rtk {
+
+using rtd::Float4;
+
+#define DEVI __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------------
+// small math
+// ------------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+DEVI V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEVI V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEVI V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEVI V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+DEVI V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEVI V3 operator*(V3 a, float t) { return v3(a.x * t, a.y * t, a.z * t); }
+DEVI V3 operator*(float t, V3 a) { return v3(a.x * t, a.y * t, a.z * t); }
+DEVI V3 operator/(V3 a, float t) { return v3(a.x / t, a.y / t, a.z / t); }   // vec3.rs:181: component-wise divide
+DEVI float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEVI V3 cross(V3 u, V3 v) { return v3(u.y * v.z - u.z * v.y, -(u.x * v.z - u.z * v.x), u.x * v.y - u.y * v.x); }   // vec3.rs:68-76
+DEVI float len2(V3 a) { return dot(a, a); }
+DEVI float len(V3 a) { return sqrtf(len2(a)); }
+DEVI V3 unit(V3 a) { return a / len(a); }                                   // vec3.rs:29-31
+DEVI V3 reflect(V3 v, V3 n) { return v - 2.0f * dot(v, n) * n; }            // vec3.rs:115-117
+DEVI V3 refract(V3 uv, V3 n, float eta) {                                    // vec3.rs:246-251
+    float cos_theta = fminf(dot(-uv, n), 1.0f);
+    V3 perp = eta * (uv + cos_theta * n);
+    V3 par = -sqrtf(fabsf(1.0f - len2(perp))) * n;
+    return perp + par;
+}
+DEVI float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInf = __builtin_huge_valf();
+constexpr float kTMin = 0.001f;   // main.rs:74
+
+// ------------------------------------------------------------------------------------------------
+// RNG — SplitMix64 over a per-path counter (replaces rand::random, rt_weekend.rs:8-19).
+// The draw ORDER is the reference's (SURVEY.md §8a' table); see DESIGN.md "RNG".
+// ------------------------------------------------------------------------------------------------
+constexpr uint64_t kGamma = 0x9E3779B97F4A7C15ull;
+DEVI uint64_t fin(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+DEVI uint64_t path_base(uint64_t seed, uint64_t pixel_index, uint64_t sample_index) {
+    uint64_t h = fin(seed + kGamma * (pixel_index + 1));
+    return fin(h + 0xD1B54A32D192ED03ull * (sample_index + 1));
+}
+DEVI uint64_t medium_bits(uint64_t base, uint32_t segment, uint32_t medium_id) {
+    return fin(base ^ fin(0xA0761D6478BD642Full * (uint64_t)(segment + 1) + 0xE7037ED1A0B428DBull * (uint64_t)(medium_id + 1)));
+}
+DEVI float u01(uint64_t z) { return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f); }
+struct Rng {
+    uint64_t s;
+    DEVI uint64_t next64() { s += kGamma; return fin(s); }
+    DEVI float rnd() { return u01(next64()); }                               // rt_weekend.rs:8-11
+    DEVI float range(float lo, float hi) { return lo + (hi - lo) * rnd(); }  // rt_weekend.rs:13-15
+};
+DEVI V3 random_in_unit_sphere(Rng& g) {                                      // vec3.rs:78-86
+    for (;;) {
+        float a = g.range(-1.f, 1.f), b = g.range(-1.f, 1.f), c = g.range(-1.f, 1.f);
+        V3 p = v3(a, b, c);
+        if (len2(p) >= 1.0f) continue;
+        return p;
+    }
+}
+DEVI V3 random_cosine_direction(Rng& g) {                                    // vec3.rs:253-262
+    float r1 = g.rnd(), r2 = g.rnd();
+    float z = sqrtf(1.0f - r2);
+    float phi = 2.0f * kPi * r1;
+    float s, c; sincosf(phi, &s, &c);
+    float sr = sqrtf(r2);
+    return v3(c * sr, s * sr, z);
+}
+DEVI V3 random_to_sphere(Rng& g, float radius, float distance_sq) {          // pdf.rs:82-91
+    float r1 = g.rnd(), r2 = g.rnd();
+    float z = 1.0f + r2 * (sqrtf(1.0f - radius * radius / distance_sq) - 1.0f);
+    float phi = 2.0f * kPi * r1;
+    float s, c; sincosf(phi, &s, &c);
+    float q = sqrtf(1.0f - z * z);
+    return v3(c * q, s * q, z);
+}
+struct Onb { V3 u, v, w; };
+DEVI Onb onb_from_w(V3 n) {                                                  // onb.rs:19-30
+    Onb o;
+    o.w = unit(n);
+    V3 a = (fabsf(o.w.x) > 0.9f) ? v3(0, 1, 0) : v3(1, 0, 0);
+    o.v = unit(cross(o.w, a));
+    o.u = cross(o.w, o.v);
+    return o;
+}
+DEVI V3 onb_local(const Onb& o, V3 a) { return a.x * o.u + a.y * o.v + a.z * o.w; }   // onb.rs:40-42
+
+// ------------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------------
+DEVI uint32_t lane_rank(uint64_t mask) {   // number of set bits of `mask` below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+DEVI uint32_t first_lane_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// ------------------------------------------------------------------------------------------------
+// instance transforms (hittable.rs:76-85, 147-176)
+// ------------------------------------------------------------------------------------------------
+DEVI void xform_ray(const rtd::Xform& x, V3 o, V3 d, V3& ol, V3& dl) {
+    V3 m = v3(o.x - x.off[0], o.y - x.off[1], o.z - x.off[2]);               // Translate: origin - offset
+    ol = v3(x.cos_t * m.x - x.sin_t * m.z, m.y, x.sin_t * m.x + x.cos_t * m.z);   // RotateY :151-152
+    dl = v3(x.cos_t * d.x - x.sin_t * d.z, d.y, x.sin_t * d.x + x.cos_t * d.z);   // :154-155
+}
+DEVI V3 xform_point_back(const rtd::Xform& x, V3 p) {
+    V3 r = v3(x.cos_t * p.x + x.sin_t * p.z, p.y, -x.sin_t * p.x + x.cos_t * p.z);   // :166-167
+    return v3(r.x + x.off[0], r.y + x.off[1], r.z + x.off[2]);                       // Translate :81
+}
+DEVI V3 xform_normal_back(const rtd::Xform& x, V3 n) {
+    return v3(x.cos_t * n.x + x.sin_t * n.z, n.y, -x.sin_t * n.x + x.cos_t * n.z);   // :169-170
+}
+
+// ------------------------------------------------------------------------------------------------
+// primitive tests (closest-hit interval [tmin, tmax], both ends inclusive like the reference)
+// ------------------------------------------------------------------------------------------------
+// Sphere::hit (sphere.rs:41-65). The quadratic's coefficients are formed in f64: the reference is
+// f64 throughout, and in f32 `oc.length_squared() - r*r` loses ~0.1 absolute for the r = 1000
+// ground sphere, which turns into false self-hits beyond t_min = 0.001 at grazing angles.
+DEVI bool sphere_roots(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax, float& t) {
+    const double ocx = (double)o.x - (double)c.x, ocy = (double)o.y - (double)c.y, ocz = (double)o.z - (double)c.z;
+    const double half_b = ocx * (double)d.x + ocy * (double)d.y + ocz * (double)d.z;
+    const double cc = ocx * ocx + ocy * ocy + ocz * ocz - (double)r * (double)r;
+    const double det = half_b * half_b - (double)a * cc;
+    if (det < 0.0) return false;
+    const double sq = sqrt(det);
+    float root = (float)((-half_b - sq) / (double)a);
+    if (root < tmin || tmax < root) {
+        root = (float)((-half_b + sq) / (double)a);
+        if (root < tmin || tmax < root) return false;
+    }
+    t = root;
+    return true;
+}
+DEVI V3 moving_center(Float4 m0, Float4 m1, Float4 m2, float time) {           // moving_sphere.rs:36-39
+    const float f = (time - m1.w) / (m2.x - m1.w);
+    return v3(m0.x + f * (m1.x - m0.x), m0.y + f * (m1.y - m0.y), m0.z + f * (m1.z - m0.z));
+}
+// XyRect/XzRect/YzRect::hit (aarect.rs:31-48, 81-98, 150-167)
+DEVI bool rect_hit(V3 o, V3 d, Float4 r0, Float4 r1, float tmin, float tmax, float& t, float& ha, float& hb) {
+    const int kaxis = (int)r1.y;
+    const int ia = kaxis == 0 ? 1 : 0, ib = kaxis == 2 ? 1 : 2;
+    const float tt = (r1.x - comp(o, kaxis)) / comp(d, kaxis);
+    if (tt < tmin || tt > tmax) return false;
+    if (!(fabsf(tt) < kInf)) return false;   // never accept t = inf / NaN (ray parallel to the plane)
+    const float a = comp(o, ia) + tt * comp(d, ia);
+    const float b = comp(o, ib) + tt * comp(d, ib);
+    if (a < r0.x || a > r0.y || b < r0.z || b > r0.w) return false;
+    t = tt; ha = a; hb = b;
+    return true;
+}
+// Triangle (not in the reference): Moeller-Trumbore, inclusive interval, u,v = barycentrics
+DEVI bool tri_hit(V3 o, V3 d, V3 v0, V3 v1, V3 v2, float tmin, float tmax, float& t, float& bu, float& bv) {
+    const V3 e1 = v1 - v0, e2 = v2 - v0;
+    const V3 pv = cross(d, e2);
+    const float det = dot(e1, pv);
+    if (det == 0.0f) return false;
+    const float inv = 1.0f / det;
+    const V3 tv = o - v0;
+    const float u = dot(tv, pv) * inv;
+    if (u < 0.0f || u > 1.0f) return false;
+    const V3 qv = cross(tv, e1);
+    const float v = dot(d, qv) * inv;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float tt = dot(e2, qv) * inv;
+    if (tt < tmin || tt > tmax || !(fabsf(tt) < kInf)) return false;
+    t = tt; bu = u; bv = v;
+    return true;
+}
+
+DEVI V3 f4xyz(Float4 f) { return v3(f.x, f.y, f.z); }
+
+// ConstantMedium::hit (constant_medium.rs:31-71). Boundary = sphere or box, optionally under an
+// instance transform. `xi` is the free-path draw keyed by (path, segment, medium).
+DEVI bool boundary_hit(const SceneDev& sc, const rtd::Medium& m, V3 o, V3 d, float a, float tmin, float tmax, float& t) {
+    if (m.boundary_type == rtd::LT_SPHERE) {
+        const Float4 s = sc.spheres[m.boundary_first];
+        return sphere_roots(o, d, a, f4xyz(s), s.w, tmin, tmax, t);
+    }
+    bool any = false; float best = tmax;
+    for (uint32_t k = 0; k < m.boundary_count; ++k) {
+        const Float4 r0 = sc.rects[2 * (m.boundary_first + k)], r1 = sc.rects[2 * (m.boundary_first + k) + 1];
+        float tt, ha, hb;
+        if (rect_hit(o, d, r0, r1, tmin, best, tt, ha, hb)) { any = true; best = tt; }
+    }
+    t = best;
+    return any;
+}
+DEVI bool medium_hit(const SceneDev& sc, const rtd::Medium& m, V3 ow, V3 dw, float tmin, float tmax, float xi, float& t) {
+    V3 o = ow, d = dw;
+    if (m.boundary_xform) xform_ray(sc.xforms[m.boundary_xform], ow, dw, o, d);
+    const float a = len2(d);
+    float t1, t2;
+    if (!boundary_hit(sc, m, o, d, a, -kInf, kInf, t1)) return false;
+    if (!boundary_hit(sc, m, o, d, a, t1 + 0.0001f, kInf, t2)) return false;
+    if (t1 < tmin) t1 = tmin;
+    if (t2 > tmax) t2 = tmax;
+    if (t1 >= t2) return false;
+    if (t1 < 0.0f) t1 = 0.0f;
+    const float ray_length = sqrtf(a);
+    const float distance_inside_boundary = (t2 - t1) * ray_length;
+    const float hit_distance = m.neg_inv_density * logf(xi);
+    if (hit_distance > distance_inside_boundary) return false;
+    t = t1 + hit_distance / ray_length;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_extend — world.hit for the whole pool
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kChunk = 256;   // rays a wave takes from the queue head per atomic
+constexpr int kSteps = 8;          // node visits between refill checks
+
+template <bool LDS, uint32_t FEAT, bool COUNT>
+__global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
+                                                 uint32_t* __restrict__ head, unsigned long long* __restrict__ counters,
+                                                 RenderDev rd) {
+    extern __shared__ float4 lds[];
+    const uint32_t n_nodes = sc.n_nodes;
+    const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
+    const float4* spheres = reinterpret_cast<const float4*>(sc.spheres);
+    if (LDS) {
+        // stage the node records and the sphere records (the whole BVH for book-1-sized scenes)
+        const uint32_t n4 = 2 * n_nodes, s4 = sc.n_spheres;
+        for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) lds[i] = nodes[i];
+        for (uint32_t i = threadIdx.x; i < s4; i += blockDim.x) lds[n4 + i] = spheres[i];
+        __syncthreads();
+        nodes = lds; spheres = lds + n4;
+    }
+    const uint32_t count = *count_ptr;
+    uint32_t w_next = 0, w_end = 0;
+    bool exhausted = false;
+
+    bool have = false;
+    uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE;
+    float tmax = kInf, tm = 0.f, a = 1.f;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0), oi = v3(0, 0, 0);
+    V3 ow = o, dw = d;                 // world ray while inside an instance transform
+    uint64_t mkey = 0; uint32_t seg = 0;
+    unsigned long long c_nodes = 0, c_prims[RT_N_PRIM_TYPES_K] = {0, 0, 0, 0, 0, 0};
+
+    for (;;) {
+        const uint64_t idle = __ballot(!have);
+        if (idle != 0ull && !exhausted) {
+            uint32_t avail = w_end - w_next;
+            if (avail == 0u) {
+                uint32_t start = 0;
+                if ((threadIdx.x & 63u) == 0u) start = atomicAdd(head, kChunk);
+                start = first_lane_u32(start);
+                if (start >= count) exhausted = true;
+                else { w_next = start; w_end = min(start + kChunk, count); avail = w_end - w_next; }
+            }
+            if (avail != 0u) {
+                const uint32_t rank = lane_rank(idle);
+                if (!have && rank < avail) {
+                    slot = w_next + rank;
+                    const Float4 ro = pool.ray_o[slot], rdv = pool.ray_d[slot];
+                    o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
+                    inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+                    a = len2(d);
+                    if (FEAT & F_XFORM) { ow = o; dw = d; }
+                    if (FEAT & F_MEDIUM) {
+                        const Float4 s2 = pool.s2[slot], s3 = pool.s3[slot];
+                        seg = __float_as_uint(s2.z) & 0xFFu;
+                        mkey = (uint64_t)__float_as_uint(s3.y) | ((uint64_t)__float_as_uint(s3.z) << 32);
+                    }
+                    tmax = kInf; node = 0; hit_prim = rtd::HIT_NONE; have = true;
+                }
+                const uint32_t n_idle = (uint32_t)__popcll(idle);
+                w_next += min(n_idle, avail);
+            }
+        }
+        if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
+
+#pragma unroll 1
+        for (int step = 0; step < kSteps; ++step) {
+            if (have) {
+                if (node >= n_nodes) {
+                    pool.hit[slot] = make_uint2(__float_as_uint(tmax), hit_prim);
+                    have = false;
+                } else {
+                    const float4 n0 = nodes[2 * node], n1 = nodes[2 * node + 1];
+                    const uint32_t skip = __float_as_uint(n0.w), leaf = __float_as_uint(n1.w);
+                    // Aabb::hit (aabb.rs:31-55, interval carried across axes). min/max ignore a NaN
+                    // operand (0*inf), which keeps the box — conservative, like the reference.
+                    const float tx0 = fmaf(n0.x, inv.x, -oi.x), tx1 = fmaf(n1.x, inv.x, -oi.x);
+                    const float ty0 = fmaf(n0.y, inv.y, -oi.y), ty1 = fmaf(n1.y, inv.y, -oi.y);
+                    const float tz0 = fmaf(n0.z, inv.z, -oi.z), tz1 = fmaf(n1.z, inv.z, -oi.z);
+                    const float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), kTMin));
+                    const float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+                    const bool boxhit = tnear <= tfar * 1.0000004f;   // padded by 3 ulp: never cull a true hit
+                    if (COUNT) { if (n0.x > -kInf) c_nodes++; }
+                    if (boxhit) {
+                        if (leaf != 0u) {
+                            const uint32_t type = leaf >> 28, cnt = (leaf >> 24) & 15u, first = leaf & rtd::LEAF_MAX_FIRST;
+                            if (type == rtd::LT_SPHERE) {
+                                for (uint32_t k = 0; k < cnt; ++k) {
+                                    const float4 s = spheres[first + k];
+                                    float t;
+                                    if (COUNT) c_prims[0]++;
+                                    if (sphere_roots(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t)) { tmax = t; hit_prim = (rtd::LT_SPHERE << 28) | (first + k); }
+                                }
+                            } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
+                                for (uint32_t k = 0; k < cnt; ++k) {
+                                    const Float4 r0 = sc.rects[2 * (first + k)], r1 = sc.rects[2 * (first + k) + 1];
+                                    float t, ha, hb;
+                                    if (COUNT) c_prims[2]++;
+                                    if (rect_hit(o, d, r0, r1, kTMin, tmax, t, ha, hb)) { tmax = t; hit_prim = (rtd::LT_RECT << 28) | (first + k); }
+                                }
+                            } else if ((FEAT & F_MOVING) && type == rtd::LT_MOVING) {
+                                for (uint32_t k = 0; k < cnt; ++k) {
+                                    const Float4 m0 = sc.moving[3 * (first + k)], m1 = sc.moving[3 * (first + k) + 1], m2 = sc.moving[3 * (first + k) + 2];
+                                    float t;
+                                    if (COUNT) c_prims[1]++;
+                                    if (sphere_roots(o, d, a, moving_center(m0, m1, m2, tm), m0.w, kTMin, tmax, t)) { tmax = t; hit_prim = (rtd::LT_MOVING << 28) | (first + k); }
+                                }
+                            } else if ((FEAT & F_TRI) && type == rtd::LT_TRI) {
+                                for (uint32_t k = 0; k < cnt; ++k) {
+                                    const Float4 t0 = sc.tris[3 * (first + k)], t1 = sc.tris[3 * (first + k) + 1], t2 = sc.tris[3 * (first + k) + 2];
+                                    float t, bu, bv;
+                                    if (COUNT) c_prims[3]++;
+                                    if (tri_hit(o, d, f4xyz(t0), f4xyz(t1), f4xyz(t2), kTMin, tmax, t, bu, bv)) { tmax = t; hit_prim = (rtd::LT_TRI << 28) | (first + k); }
+                                }
+                            } else if ((FEAT & F_MEDIUM) && type == rtd::LT_MEDIUM) {
+                                const rtd::Medium m = sc.media[first];
+                                const float xi = u01(medium_bits(mkey, seg, m.medium_id));
+                                float t;
+                                if (COUNT) c_prims[4]++;
+                                const V3 mo = (FEAT & F_XFORM) ? ow : o, md = (FEAT & F_XFORM) ? dw : d;
+                                if (medium_hit(sc, m, mo, md, kTMin, tmax, xi, t)) { tmax = t; hit_prim = (rtd::LT_MEDIUM << 28) | first; }
+                            } else if ((FEAT & F_XFORM) && (type == rtd::LT_ENTER || type == rtd::LT_EXIT)) {
+                                if (first == 0u) { o = ow; d = dw; }
+                                else xform_ray(sc.xforms[first], ow, dw, o, d);
+                                inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                                oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+                                if (COUNT) { if (type == rtd::LT_ENTER) c_prims[5]++; }
+                            }
+                        }
+                        node = node + 1u;
+                    } else {
+                        node = skip;
+                    }
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        // one atomic per wave and counter
+        for (int off = 32; off > 0; off >>= 1) {
+            c_nodes += __shfl_down(c_nodes, off);
+            for (int k = 0; k < RT_N_PRIM_TYPES_K; ++k) c_prims[k] += __shfl_down(c_prims[k], off);
+        }
+        if ((threadIdx.x & 63u) == 0u) {
+            atomicAdd(&counters[CTR_NODE_TESTS], c_nodes);
+            for (int k = 0; k < RT_N_PRIM_TYPES_K; ++k) if (c_prims[k]) atomicAdd(&counters[CTR_PRIM_TESTS + k], c_prims[k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// work items, camera rays
+// ------------------------------------------------------------------------------------------------
+struct WorkItem { uint32_t x, y, blk; bool valid; };
+DEVI WorkItem decode_work(const RenderDev& rd, uint32_t w) {
+    const uint32_t ts2 = rd.tile_size * rd.tile_size;
+    const uint32_t pix = w % ts2;
+    const uint32_t q = w / ts2;
+    const uint32_t blk = q % rd.n_blocks;
+    const uint32_t lt = q / rd.n_blocks;
+    const uint32_t tile = rd.shard_index + lt * rd.shard_count;
+    const uint32_t tx = tile % rd.tiles_x, ty = tile / rd.tiles_x;
+    // 8x8 pixel squares inside the tile: one wave's 64 consecutive items cover a square
+    const uint32_t sq = pix >> 6, in = pix & 63u, sq_per_row = rd.tile_size >> 3;
+    const uint32_t px = (sq % sq_per_row) * 8u + (in & 7u), py = (sq / sq_per_row) * 8u + (in >> 3);
+    WorkItem it;
+    it.x = tx * rd.tile_size + px; it.y = ty * rd.tile_size + py; it.blk = blk;
+    it.valid = it.x < rd.width && it.y < rd.height;
+    return it;
+}
+
+// One new sample: jitter (main.rs:752-753) then Camera::get_ray (camera.rs:60-70).
+DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t sample, Rng& g, uint64_t& base, V3& o, V3& d, float& tm) {
+    const uint64_t pixel_index = (uint64_t)y * rd.width + x;
+    base = path_base(rd.seed, pixel_index, sample);
+    g.s = base;
+    const float ju = g.rnd(), jv = g.rnd();
+    const uint32_t j = rd.height - 1u - y;                       // main.rs:733
+    const float u = ((float)x + ju) / (float)(rd.width - 1u);    // main.rs:752
+    const float v = ((float)j + jv) / (float)(rd.height - 1u);   // main.rs:753
+    // random_in_unit_disk (vec3.rs:101-113): drawn even when lens_radius == 0
+    float px, py;
+    for (;;) { px = g.range(-1.f, 1.f); py = g.range(-1.f, 1.f); if (px * px + py * py >= 1.0f) continue; break; }
+    const V3 rdk = v3(rd.cam_lens_radius * px, rd.cam_lens_radius * py, 0.f);
+    const V3 cu = v3(rd.cam_u[0], rd.cam_u[1], rd.cam_u[2]), cv = v3(rd.cam_v[0], rd.cam_v[1], rd.cam_v[2]);
+    const V3 offset = cu * rdk.x + cv * rdk.y;
+    const V3 org = v3(rd.cam_origin[0], rd.cam_origin[1], rd.cam_origin[2]);
+    const V3 llc = v3(rd.cam_llc[0], rd.cam_llc[1], rd.cam_llc[2]);
+    const V3 hor = v3(rd.cam_horizontal[0], rd.cam_horizontal[1], rd.cam_horizontal[2]);
+    const V3 ver = v3(rd.cam_vertical[0], rd.cam_vertical[1], rd.cam_vertical[2]);
+    o = org + offset;
+    d = llc + hor * u + ver * v - org - offset;
+    tm = g.range(rd.cam_time0, rd.cam_time1);                    // drawn even when time0 == time1
+}
+
+struct PathState {
+    V3 T, L, acc;
+    uint32_t work, sdepth;   // sdepth = sample_in_block << 8 | depth
+    uint64_t rng, base;
+};
+DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const PathState& s) {
+    p.ray_o[i] = Float4{o.x, o.y, o.z, tm};
+    p.ray_d[i] = Float4{d.x, d.y, d.z, 0.f};
+    p.s0[i] = Float4{s.T.x, s.T.y, s.T.z, s.L.x};
+    p.s1[i] = Float4{s.L.y, s.L.z, s.acc.x, s.acc.y};
+    p.s2[i] = Float4{s.acc.z, __uint_as_float(s.work), __uint_as_float(s.sdepth), __uint_as_float((uint32_t)s.rng)};
+    p.s3[i] = Float4{__uint_as_float((uint32_t)(s.rng >> 32)), __uint_as_float((uint32_t)s.base), __uint_as_float((uint32_t)(s.base >> 32)), 0.f};
+}
+
+// Take work items until one maps to a pixel inside the image (edge tiles), or the queue is empty.
+// Wave-aggregated: one atomicAdd per wave per round. Returns false if no work is left.
+DEVI bool take_work(const RenderDev& rd, uint32_t* next_work, bool want, uint32_t& work, WorkItem& it) {
+    bool got = false;
+    for (;;) {
+        const uint64_t m = __ballot(want && !got);
+        if (m == 0ull) break;
+        uint32_t base = 0;
+        const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+        if ((threadIdx.x & 63u) == leader) base = atomicAdd(next_work, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, (int)leader);
+        if (want && !got) {
+            const uint32_t w = base + lane_rank(m);
+            if (w >= rd.total_items) want = false;
+            else { it = decode_work(rd, w); if (it.valid) { work = w; got = true; } }
+        }
+    }
+    return got;
+}
+
+__global__ void __launch_bounds__(256) k_generate(PoolDev pool, RenderDev rd, uint32_t n_init, uint32_t* __restrict__ next_work, uint32_t* __restrict__ out_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool want = i < n_init;
+    uint32_t work = 0; WorkItem it{};
+    const bool got = take_work(rd, next_work, want, work, it);
+    // dense write of the slots that got work
+    const uint64_t m = __ballot(got);
+    if (m == 0ull) return;
+    uint32_t base = 0;
+    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+    if ((threadIdx.x & 63u) == leader) base = atomicAdd(out_count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, (int)leader);
+    if (got) {
+        PathState s; Rng g; V3 o, d; float tm;
+        new_camera_ray(rd, it.x, it.y, it.blk * rd.block_len, g, s.base, o, d, tm);
+        s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); s.acc = v3(0, 0, 0); s.work = work; s.sdepth = 0; s.rng = g.s;
+        store_path(pool, base + lane_rank(m), o, d, tm, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// textures (texture.rs, perlin.rs)
+// ------------------------------------------------------------------------------------------------
+DEVI float perlin_noise(const rtd::PerlinTable& pt, V3 p) {                    // perlin.rs:26-52
+    float u = p.x - floorf(p.x), v = p.y - floorf(p.y), w = p.z - floorf(p.z);
+    u = u * u * (3.f - 2.f * u); v = v * v * (3.f - 2.f * v); w = w * w * (3.f - 2.f * w);   // :30-32 (first smoothing)
+    const int i = (int)floorf(p.x), j = (int)floorf(p.y), k = (int)floorf(p.z);
+    const float uu = u * u * (3.f - 2.f * u), vv = v * v * (3.f - 2.f * v), ww = w * w * (3.f - 2.f * w);   // perlin_interp :68-70 (second)
+    float accum = 0.f;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                const Float4 c = pt.ranvec[pt.perm_x[(i + di) & 255] ^ pt.perm_y[(j + dj) & 255] ^ pt.perm_z[(k + dk) & 255]];
+                const V3 weight_v = v3(u - (float)di, v - (float)dj, w - (float)dk);
+                accum += ((float)di * uu + (1.f - (float)di) * (1.f - uu)) * ((float)dj * vv + (1.f - (float)dj) * (1.f - vv)) *
+                         ((float)dk * ww + (1.f - (float)dk) * (1.f - ww)) * dot(v3(c.x, c.y, c.z), weight_v);
+            }
+    return accum;
+}
+DEVI float perlin_turb(const rtd::PerlinTable& pt, V3 p) {                     // perlin.rs:86-98
+    float accum = 0.f, weight = 1.f; V3 tp = p;
+    for (int i = 0; i < 7; ++i) { accum += weight * perlin_noise(pt, tp); weight *= 0.5f; tp = tp * 2.0f; }
+    return fabsf(accum);
+}
+DEVI V3 texture_value(const SceneDev& sc, uint32_t id, float u, float v, V3 p) {
+    rtd::Texture t = sc.textures[id];
+    if (t.kind == rtd::TK_CHECKER) {                                           // texture.rs:60-69
+        const float sines = sinf(10.f * p.x) * sinf(10.f * p.y) * sinf(10.f * p.z);
+        t = sc.textures[sines < 0.f ? t.b : t.a];
+        if (t.kind == rtd::TK_CHECKER) t = sc.textures[t.a];                   // one nesting level only
+    }
+    if (t.kind == rtd::TK_SOLID) return v3(t.color[0], t.color[1], t.color[2]);   // texture.rs:34-38
+    if (t.kind == rtd::TK_NOISE) {                                             // texture.rs:90-96
+        const float s = 0.5f * (1.f + sinf(t.scale * p.z + 10.f * perlin_turb(sc.perlins[t.a], p)));
+        return v3(s, s, s);
+    }
+    // image, texture.rs:117-140
+    if (t.a < 0) return v3(0.f, 1.f, 1.f);
+    const rtd::Image im = sc.images[t.a];
+    if (im.width == 0u) return v3(0.f, 1.f, 1.f);
+    u = fminf(fmaxf(u, 0.f), 1.f);
+    v = 1.f - fminf(fmaxf(v, 0.f), 1.f);
+    uint32_t i = (uint32_t)(u * (float)im.width), j = (uint32_t)(v * (float)im.height);
+    if (i >= im.width) i = im.width - 1u;
+    if (j >= im.height) j = im.height - 1u;
+    const uint8_t* px = sc.image_bytes + im.offset + ((size_t)j * im.width + i) * 3u;
+    const float cs = 1.f / 255.f;
+    return v3(cs * (float)px[0], cs * (float)px[1], cs * (float)px[2]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// lights: HittableList::pdf_value / random over XzRect and Sphere (hittable_list.rs:73-84)
+// ------------------------------------------------------------------------------------------------
+DEVI float light_pdf_value(const rtd::Light& l, V3 o, V3 v, unsigned long long& tests) {
+    if (l.kind == rtd::LK_XZRECT) {                                            // aarect.rs:107-117
+        tests++;
+        const Float4 r0 = Float4{l.p[0], l.p[1], l.p[2], l.p[3]}, r1 = Float4{l.p[4], 1.f, 0.f, 0.f};
+        float t, ha, hb;
+        if (!rect_hit(o, v, r0, r1, kTMin, kInf, t, ha, hb)) return 0.f;
+        const float area = (l.p[1] - l.p[0]) * (l.p[3] - l.p[2]);
+        const float distance_squared = t * t * len2(v);
+        // rec.normal = +-(0,1,0) against the ray; |dot| makes the sign irrelevant
+        const float cosine = fabsf(v.y / len(v));
+        return distance_squared / cosine / area;
+    }
+    if (l.kind == rtd::LK_SPHERE) {                                            // sphere.rs:75-84
+        tests++;
+        const V3 c = v3(l.p[0], l.p[1], l.p[2]); const float r = l.p[3];
+        float t;
+        if (!sphere_roots(o, v, len2(v), c, r, kTMin, kInf, t)) return 0.f;
+        const float cos_theta_max = sqrtf(1.f - r * r / len2(c - o));
+        const float solid_angle = 2.f * kPi * (1.f - cos_theta_max);
+        return 1.f / solid_angle;
+    }
+    return 0.f;                                                                // hittable.rs:54-56
+}
+DEVI V3 light_random(const rtd::Light& l, V3 o, Rng& g) {
+    if (l.kind == rtd::LK_XZRECT) {                                            // aarect.rs:118-125
+        const float rx = g.range(l.p[0], l.p[1]);
+        const float rz = g.range(l.p[2], l.p[3]);
+        return v3(rx, l.p[4], rz) - o;
+    }
+    if (l.kind == rtd::LK_SPHERE) {                                            // sphere.rs:85-90
+        const V3 c = v3(l.p[0], l.p[1], l.p[2]);
+        const V3 direction = c - o;
+        const float distance_sq = len2(direction);
+        const Onb uvw = onb_from_w(direction);
+        return onb_local(uvw, random_to_sphere(g, l.p[3], distance_sq));
+    }
+    return v3(1.f, 0.f, 0.f);                                                  // hittable.rs:57-59
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade
+// ------------------------------------------------------------------------------------------------
+DEVI void sphere_uv(V3 p, float& u, float& v) {                                // sphere.rs:32-37
+    const float theta = acosf(-p.y);
+    const float phi = atan2f(-p.z, p.x) + kPi;
+    u = phi / (2.f * kPi);
+    v = theta / kPi;
+}
+
+template <uint32_t FEAT, bool COUNT>
+__global__ void __launch_bounds__(256) k_shade(SceneDev sc, PoolDev in, PoolDev out, RenderDev rd, const uint32_t* __restrict__ count_in_ptr,
+                                                uint32_t* __restrict__ count_out, uint32_t* __restrict__ next_work,
+                                                unsigned long long* __restrict__ counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t count_in = *count_in_ptr;
+    bool alive = i < count_in;
+    PathState s{}; V3 o = v3(0, 0, 0), d = v3(0, 0, 1); float tm = 0.f;
+    unsigned long long c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
+    bool want_work = false;
+    if (alive) {
+        const Float4 ro = in.ray_o[i], rdv = in.ray_d[i], s0 = in.s0[i], s1 = in.s1[i], s2 = in.s2[i], s3 = in.s3[i];
+        const uint2 hit = in.hit[i];
+        o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
+        s.T = v3(s0.x, s0.y, s0.z); s.L = v3(s0.w, s1.x, s1.y); s.acc = v3(s1.z, s1.w, s2.x);
+        s.work = __float_as_uint(s2.y); s.sdepth = __float_as_uint(s2.z);
+        s.rng = (uint64_t)__float_as_uint(s2.w) | ((uint64_t)__float_as_uint(s3.x) << 32);
+        s.base = (uint64_t)__float_as_uint(s3.y) | ((uint64_t)__float_as_uint(s3.z) << 32);
+        Rng g; g.s = s.rng;
+        uint32_t depth = s.sdepth & 0xFFu, sib = s.sdepth >> 8;
+        bool finished = false;
+
+        if (hit.y == rtd::HIT_NONE) {
+            // main.rs:74-76: the miss returns the background
+            V3 bg = v3(rd.bg[0], rd.bg[1], rd.bg[2]);
+            if (rd.bg_mode == RT_BG_SKY_GRADIENT_K) {
+                const V3 ud = unit(d);
+                const float t = 0.5f * (ud.y + 1.0f);
+                bg = (1.0f - t) * v3(1.f, 1.f, 1.f) + t * bg;
+            }
+            s.L = s.L + s.T * bg;
+            finished = true;
+        } else {
+            // ---- rebuild the HitRecord (hittable.rs:11-19) from (ray, t, primitive) ----
+            const float t = __uint_as_float(hit.x);
+            const uint32_t type = hit.y >> 28, idx = hit.y & rtd::LEAF_MAX_FIRST;
+            uint32_t meta;
+            V3 p, n; float hu = 0.f, hv = 0.f; bool ff;
+            if ((FEAT & F_MEDIUM) && type == rtd::LT_MEDIUM) {
+                meta = sc.media[idx].meta;
+                p = o + d * t; n = v3(1.f, 0.f, 0.f); ff = true;                // constant_medium.rs:62-66
+            } else {
+                meta = type == rtd::LT_SPHERE ? sc.sphere_meta[idx]
+                     : ((FEAT & F_RECT) && type == rtd::LT_RECT) ? sc.rect_meta[idx]
+                     : ((FEAT & F_MOVING) && type == rtd::LT_MOVING) ? sc.moving_meta[idx]
+                     : ((FEAT & F_TRI) && type == rtd::LT_TRI) ? sc.tri_meta[idx] : 0u;
+                const uint32_t xf = (FEAT & F_XFORM) ? (meta >> 24) : 0u;
+                V3 ol = o, dl = d;
+                if ((FEAT & F_XFORM) && xf) xform_ray(sc.xforms[xf], o, d, ol, dl);
+                V3 outward;
+                if (type == rtd::LT_SPHERE) {
+                    const Float4 sp = sc.spheres[idx];
+                    p = ol + dl * t;                                            // sphere.rs:59
+                    outward = (p - v3(sp.x, sp.y, sp.z)) / sp.w;                // :60
+                    if (FEAT & F_TEX) sphere_uv(outward, hu, hv);               // :62 (only textures read u,v)
+                } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
+                    const Float4 r0 = sc.rects[2 * idx], r1 = sc.rects[2 * idx + 1];
+                    const int kaxis = (int)r1.y; const int ia = kaxis == 0 ? 1 : 0, ib = kaxis == 2 ? 1 : 2;
+                    p = ol + dl * t;                                            // aarect.rs:46
+                    const float a = comp(p, ia), b = comp(p, ib);
+                    hu = (a - r0.x) / (r0.y - r0.x); hv = (b - r0.z) / (r0.w - r0.z);   // :41-42
+                    // on the plane exactly: the f64 reference's r.at(t) lands within 1e-13 of k
+                    if (kaxis == 0) p.x = r1.x; else if (kaxis == 1) p.y = r1.x; else p.z = r1.x;
+                    outward = v3(kaxis == 0 ? 1.f : 0.f, kaxis == 1 ? 1.f : 0.f, kaxis == 2 ? 1.f : 0.f);
+                } else if ((FEAT & F_MOVING) && type == rtd::LT_MOVING) {
+                    const Float4 m0 = sc.moving[3 * idx], m1 = sc.moving[3 * idx + 1], m2 = sc.moving[3 * idx + 2];
+                    p = ol + dl * t;
+                    outward = (p - moving_center(m0, m1, m2, tm)) / m0.w;       // moving_sphere.rs:58 (u,v not set: 0)
+                } else {
+                    const V3 v0 = f4xyz(sc.tris[3 * idx]), v1 = f4xyz(sc.tris[3 * idx + 1]), v2 = f4xyz(sc.tris[3 * idx + 2]);
+                    float tt, bu, bv;
+                    tri_hit(ol, dl, v0, v1, v2, -kInf, kInf, tt, bu, bv);
+                    hu = bu; hv = bv;
+                    p = ol + dl * t;
+                    outward = unit(cross(v1 - v0, v2 - v0));
+                }
+                ff = dot(dl, outward) < 0.f;                                    // set_face_normal, hittable.rs:41-48
+                n = ff ? outward : -outward;
+                if ((FEAT & F_XFORM) && xf) { p = xform_point_back(sc.xforms[xf], p); n = xform_normal_back(sc.xforms[xf], n); }
+                const uint32_t ffm = (meta >> 22) & 3u;                         // wrappers above the primitive
+                ff = ffm == 0u ? ff : (ffm == 1u ? !ff : (ffm == 2u));
+            }
+            const uint32_t mat = meta & rtd::META_MAT_MASK;
+            const Float4 ma = sc.mat_a[mat]; const uint32_t mb = sc.mat_b[mat];
+            const uint32_t kind = mb & 15u, tex = mb >> 4;
+            V3 colour = v3(ma.x, ma.y, ma.z);
+            if ((FEAT & F_TEX) && tex != rtd::TEX_INLINE && kind != rtd::MK_METAL && kind != rtd::MK_DIELECTRIC) colour = texture_value(sc, tex, hu, hv, p);
+
+            if (kind == rtd::MK_DIFFUSE_LIGHT) {
+                // emitted (material.rs:184-190); default scatter returns false -> main.rs:85-87
+                if (ff) s.L = s.L + s.T * colour;
+                finished = true;
+            } else {
+                if (kind == rtd::MK_LAMBERTIAN) {
+                    // Lambertian::scatter (material.rs:48-63): attenuation = albedo, pdf = CosinePdf(normal)
+                    const Onb uvw = onb_from_w(n);                              // pdf.rs:18-22
+                    V3 dir;
+                    float pdf_val;
+                    if ((FEAT & F_LIGHTS) && sc.n_lights) {
+                        // MixturePdf::generate (pdf.rs:73-79) over HittablePdf(lights) and the cosine pdf
+                        if (g.rnd() < 0.5f) {
+                            const uint32_t k = (uint32_t)(g.next64() % (uint64_t)sc.n_lights);   // hittable_list.rs:81-84
+                            dir = light_random(sc.lights[k], p, g);
+                        } else dir = onb_local(uvw, random_cosine_direction(g));
+                        // MixturePdf::value (pdf.rs:70-72)
+                        const float weight = 1.0f / (float)sc.n_lights;
+                        float lsum = 0.f;
+                        for (uint32_t k = 0; k < sc.n_lights; ++k) {
+                            const rtd::Light l = sc.lights[k];
+                            lsum += weight * light_pdf_value(l, p, dir, l.kind == rtd::LK_XZRECT ? c_light_rect : c_light_sphere);
+                        }
+                        const float cosine = dot(unit(dir), uvw.w);
+                        const float cpdf = cosine <= 0.f ? 0.f : cosine / kPi;   // pdf.rs:24-31
+                        pdf_val = 0.5f * lsum + 0.5f * cpdf;
+                    } else {
+                        dir = onb_local(uvw, random_cosine_direction(g));       // pdf.rs:32-34
+                        const float cosine = dot(unit(dir), uvw.w);
+                        pdf_val = cosine <= 0.f ? 0.f : cosine / kPi;
+                    }
+                    const float cosine_s = dot(n, unit(dir));                   // scattering_pdf, material.rs:64-71
+                    const float spdf = cosine_s < 0.f ? 0.f : cosine_s / kPi;
+                    s.T = s.T * colour * spdf / pdf_val;                        // main.rs:130-138 (emitted = 0)
+                    o = p; d = dir;                                             // main.rs:96 (time kept)
+                } else if (kind == rtd::MK_METAL) {
+                    // Metal::scatter (material.rs:96-107): the fuzz sphere is drawn even for fuzz 0; time := 0.0
+                    const V3 reflected = reflect(unit(d), n);
+                    const V3 fz = random_in_unit_sphere(g);
+                    s.T = s.T * colour;                                         // main.rs:89-92
+                    o = p; d = reflected + ma.w * fz; tm = 0.0f;
+                } else if (kind == rtd::MK_DIELECTRIC) {
+                    // Dielectric::scatter (material.rs:131-155)
+                    const float ir = ma.w;
+                    const float ratio = ff ? 1.0f / ir : ir;
+                    const V3 ud = unit(d);
+                    const float cos_theta = fminf(dot(-ud, n), 1.0f);
+                    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                    const bool cannot_refract = ratio * sin_theta > 1.0f;
+                    bool refl = cannot_refract;
+                    if (!refl) {                                                // `||` short-circuit: draw only if it can refract
+                        float r0 = (1.f - ratio) / (1.f + ratio); r0 *= r0;
+                        const float m = 1.f - cos_theta;
+                        const float reflectance = r0 + (1.f - r0) * (m * m * m * m * m);   // material.rs:123-127
+                        refl = reflectance > g.rnd();
+                    }
+                    d = refl ? reflect(ud, n) : refract(ud, n, ratio);
+                    o = p;
+                } else {
+                    // Isotropic::scatter (material.rs:209-219, commented spec)
+                    const V3 dir = random_in_unit_sphere(g);
+                    s.T = s.T * colour;
+                    o = p; d = dir;
+                }
+                depth++;
+                if (depth >= rd.max_depth) finished = true;                     // main.rs:71-73: the next call returns 0
+            }
+        }
+
+        if (finished) {
+            // one sample done: main.rs:772 `pixel_color += received`
+            if (COUNT) c_samples++;
+            V3 L = s.L;
+            const bool fin_ok = (fabsf(L.x) < kInf) && (fabsf(L.y) < kInf) && (fabsf(L.z) < kInf);
+            if (!fin_ok && rd.nan_policy == RT_NAN_PER_SAMPLE_K) L = v3(0.f, 0.f, 0.f);
+            s.acc = s.acc + L;
+            sib++;
+            const WorkItem it = decode_work(rd, s.work);
+            const uint32_t first_sample = it.blk * rd.block_len;
+            const uint32_t this_len = min(rd.block_len, rd.spp - first_sample);
+            if (sib < this_len) {
+                new_camera_ray(rd, it.x, it.y, first_sample + sib, g, s.base, o, d, tm);
+                s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); depth = 0;
+            } else {
+                rd.blocksum[s.work] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
+                want_work = true;
+            }
+        }
+        s.rng = g.s;
+        s.sdepth = (sib << 8) | depth;
+    }
+
+    // ---- regeneration: a slot whose block is complete draws a new work item ----
+    if (__ballot(want_work) != 0ull) {
+        uint32_t work = 0; WorkItem it{};
+        const bool got = take_work(rd, next_work, want_work, work, it);
+        if (want_work) {
+            if (got) {
+                Rng g;
+                new_camera_ray(rd, it.x, it.y, it.blk * rd.block_len, g, s.base, o, d, tm);
+                s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); s.acc = v3(0, 0, 0); s.work = work; s.sdepth = 0; s.rng = g.s;
+            } else alive = false;
+        }
+    }
+
+    // ---- compaction: survivors go to the other pool densely (wave64 ballot + prefix) ----
+    const uint64_t m = __ballot(alive);
+    if (m != 0ull) {
+        uint32_t base = 0;
+        const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+        if ((threadIdx.x & 63u) == leader) base = atomicAdd(count_out, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, (int)leader);
+        if (alive) store_path(out, base + lane_rank(m), o, d, tm, s);
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) { c_samples += __shfl_down(c_samples, off); c_light_rect += __shfl_down(c_light_rect, off); c_light_sphere += __shfl_down(c_light_sphere, off); }
+        if ((threadIdx.x & 63u) == 0u) {
+            if (c_samples) atomicAdd(&counters[CTR_SAMPLES], c_samples);
+            if (c_light_rect) atomicAdd(&counters[CTR_PRIM_TESTS + 2], c_light_rect);
+            if (c_light_sphere) atomicAdd(&counters[CTR_PRIM_TESTS + 0], c_light_sphere);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_resolve — per-pixel sum of block sums, in block order
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_resolve(RenderDev rd, float* __restrict__ out, uint32_t n_local_tiles) {
+    const uint32_t ts2 = rd.tile_size * rd.tile_size;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n_local_tiles * ts2) return;
+    const uint32_t lt = (uint32_t)(gid / ts2), pix = (uint32_t)(gid % ts2);
+    float r = 0.f, g = 0.f, b = 0.f;
+    for (uint32_t blk = 0; blk < rd.n_blocks; ++blk) {
+        const Float4 v = rd.blocksum[((uint64_t)lt * rd.n_blocks + blk) * ts2 + pix];
+        r += v.x; g += v.y; b += v.z;
+    }
+    const WorkItem it = decode_work(rd, (uint32_t)((uint64_t)lt * rd.n_blocks * ts2 + pix));
+    if (rd.shard_count <= 1u) {
+        if (it.valid) { float* q = out + ((uint64_t)it.y * rd.width + it.x) * 3u; q[0] = r; q[1] = g; q[2] = b; }
+    } else {
+        // tile-compact layout, row-major inside the tile; pixels outside the image are 0
+        const uint32_t tile = rd.shard_index + lt * rd.shard_count;
+        const uint32_t tx = tile % rd.tiles_x, ty = tile / rd.tiles_x;
+        const uint32_t px = it.x - tx * rd.tile_size, py = it.y - ty * rd.tile_size;
+        float* q = out + ((uint64_t)lt * ts2 + (uint64_t)py * rd.tile_size + px) * 3u;
+        q[0] = it.valid ? r : 0.f; q[1] = it.valid ? g : 0.f; q[2] = it.valid ? b : 0.f;
+    }
+}
+
+// write_color (main.rs:141-169) on the device
+__global__ void __launch_bounds__(256) k_write_color(const float* __restrict__ rgb_sum, uint32_t n_pixels, uint32_t spp, uint8_t* __restrict__ rgb8) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels * 3u) return;
+    float c = rgb_sum[i];
+    if (c != c) c = 0.f;
+    const float scale = 1.0f / (float)spp;
+    c = sqrtf(scale * c);
+    c = c < 0.f ? 0.f : (c > 0.999f ? 0.999f : c);
+    rgb8[i] = (uint8_t)(256.0f * c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+template <bool LDS, uint32_t FEAT>
+static hipError_t launch_extend_t(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
+                                  uint32_t* head, unsigned long long* counters, bool count, hipStream_t stream) {
+    const size_t lds_bytes = LDS ? ((size_t)sc.n_nodes * 32u + (size_t)sc.n_spheres * 16u) : 0u;
+    if (count) hipLaunchKernelGGL((k_extend<LDS, FEAT, true>), dim3(cfg.extend_blocks), dim3(256), lds_bytes, stream, sc, pool, count_ptr, head, counters, rd);
+    else hipLaunchKernelGGL((k_extend<LDS, FEAT, false>), dim3(cfg.extend_blocks), dim3(256), lds_bytes, stream, sc, pool, count_ptr, head, counters, rd);
+    return hipGetLastError();
+}
+
+hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
+                         uint32_t* head, unsigned long long* counters, bool count, hipStream_t stream) {
+    const bool simple = (cfg.features == 0u);
+    if (cfg.scene_in_lds) {
+        if (simple) return launch_extend_t<true, 0u>(cfg, sc, pool, rd, count_ptr, head, counters, count, stream);
+        return launch_extend_t<true, F_ALL>(cfg, sc, pool, rd, count_ptr, head, counters, count, stream);
+    }
+    if (simple) return launch_extend_t<false, 0u>(cfg, sc, pool, rd, count_ptr, head, counters, count, stream);
+    return launch_extend_t<false, F_ALL>(cfg, sc, pool, rd, count_ptr, head, counters, count, stream);
+}
+
+hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
+                        const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, unsigned long long* counters, bool count, hipStream_t stream) {
+    const uint32_t blocks = (max_count + 255u) / 256u;
+    if (blocks == 0u) return hipSuccess;
+    const bool simple = (cfg.features == 0u);
+    if (simple) {
+        if (count) hipLaunchKernelGGL((k_shade<0u, true>), dim3(blocks), dim3(256), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
+        else hipLaunchKernelGGL((k_shade<0u, false>), dim3(blocks), dim3(256), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
+    } else {
+        if (count) hipLaunchKernelGGL((k_shade<F_ALL, true>), dim3(blocks), dim3(256), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
+        else hipLaunchKernelGGL((k_shade<F_ALL, false>), dim3(blocks), dim3(256), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_init, uint32_t* next_work, uint32_t* out_count, hipStream_t stream) {
+    const uint32_t blocks = (n_init + 255u) / 256u;
+    if (blocks == 0u) return hipSuccess;
+    hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, stream, pool, rd, n_init, next_work, out_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const RenderDev& rd, float* out, uint32_t n_local_tiles, hipStream_t stream) {
+    const uint64_t n = (uint64_t)n_local_tiles * rd.tile_size * rd.tile_size;
+    const uint32_t blocks = (uint32_t)((n + 255u) / 256u);
+    if (blocks == 0u) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, stream, rd, out, n_local_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_write_color(const float* rgb_sum, uint32_t n_pixels, uint32_t spp, uint8_t* rgb8, hipStream_t stream) {
+    const uint32_t blocks = (n_pixels * 3u + 255u) / 256u;
+    if (blocks == 0u) return hipSuccess;
+    hipLaunchKernelGGL(k_write_color, dim3(blocks), dim3(256), 0, stream, rgb_sum, n_pixels, spp, rgb8);
+    return hipGetLastError();
+}
+
+}  // namespace rtk

@@ -1,0 +1,383 @@
+// rt_api.cpp — the C ABI of include/rt_hip.h: context, scene upload, the wavefront render loop.
+// There is no CPU fallback in this library: without a HIP device every entry point that would
+// compute returns RT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "kernels.h"
+#include "scene_compile.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes && p) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        n = std::max<size_t>(n, 256);
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace
+
+struct RtCtx {
+    int device = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    int n_cu = 256;
+    std::string err;
+    // grow-only work buffers
+    DevBuf pool[2][7]; DevBuf blocksum; DevBuf counters; DevBuf out_tmp;
+    uint32_t* h_count = nullptr;                 // pinned
+    unsigned long long* h_counters = nullptr;    // pinned
+    std::vector<hipEvent_t> events;
+};
+
+struct RtScene {
+    DevBuf nodes, spheres, sphere_meta, moving, moving_meta, rects, rect_meta, tris, tri_meta, media, xforms, mat_a, mat_b, textures, perlins, images,
+        image_bytes, lights;
+    rtk::SceneDev dev{};
+    uint32_t features = 0; bool in_lds = false;
+    int bg_mode = 0; float bg[3] = {0, 0, 0};
+    uint64_t n_nodes = 0, n_prims = 0, bytes = 0;
+};
+
+namespace {
+
+int set_err(RtCtx* ctx, int code, const std::string& msg) {
+    g_last_error = msg;
+    if (ctx) ctx->err = msg;
+    return code;
+}
+#define HIP_TRY(ctx, call)                                                                                        \
+    do {                                                                                                          \
+        hipError_t e_ = (call);                                                                                   \
+        if (e_ != hipSuccess) return set_err(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_DEVICE,          \
+                                             std::string(#call) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+template <class T> int upload(RtCtx* ctx, DevBuf& b, const std::vector<T>& v) {
+    HIP_TRY(ctx, b.ensure(v.size() * sizeof(T)));
+    if (!v.empty()) HIP_TRY(ctx, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return RT_OK;
+}
+
+struct Tiling { uint32_t ts, tiles_x, tiles_y, n_tiles, n_local; };
+int make_tiling(const RtParams& p, Tiling& t) {
+    t.ts = p.tile_size ? p.tile_size : 32u;
+    if (t.ts < 8u || t.ts > 256u || (t.ts & 7u)) return RT_ERR_INVALID;
+    t.tiles_x = (p.width + t.ts - 1) / t.ts; t.tiles_y = (p.height + t.ts - 1) / t.ts;
+    t.n_tiles = t.tiles_x * t.tiles_y;
+    const uint32_t sc = p.shard_count <= 1u ? 1u : p.shard_count, si = p.shard_count <= 1u ? 0u : p.shard_index;
+    if (si >= sc) return RT_ERR_INVALID;
+    t.n_local = t.n_tiles > si ? (t.n_tiles - si + sc - 1) / sc : 0u;
+    return RT_OK;
+}
+
+int validate_params(RtCtx* ctx, const RtParams* p) {
+    if (!p) return set_err(ctx, RT_ERR_INVALID, "params is null");
+    if (p->width < 2 || p->height < 2) return set_err(ctx, RT_ERR_INVALID, "width and height must be >= 2 (u = (i+rnd)/(W-1), main.rs:752)");
+    if (p->width > 65536 || p->height > 65536) return set_err(ctx, RT_ERR_INVALID, "image too large");
+    if (p->samples_per_pixel == 0) return set_err(ctx, RT_ERR_INVALID, "samples_per_pixel must be >= 1");
+    if (p->max_depth == 0 || p->max_depth > 255) return set_err(ctx, RT_ERR_INVALID, "max_depth must be in 1..255");
+    if (p->nan_policy > 1) return set_err(ctx, RT_ERR_INVALID, "bad nan_policy");
+    Tiling t;
+    if (make_tiling(*p, t) != RT_OK) return set_err(ctx, RT_ERR_INVALID, "bad tile_size / shard_index / shard_count");
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+const char* rt_last_error(const RtCtx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int rt_ctx_create(int device_id, void* stream, RtCtx** out_ctx) {
+    if (!out_ctx) return set_err(nullptr, RT_ERR_INVALID, "out_ctx is null");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return set_err(nullptr, RT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return set_err(nullptr, RT_ERR_INVALID, "device_id out of range");
+    RtCtx* ctx = new RtCtx();
+    ctx->device = device_id;
+    HIP_TRY(ctx, hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+    else { HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_count, 64, hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_counters, sizeof(unsigned long long) * 16, hipHostMallocDefault));
+    *out_ctx = ctx;
+    return RT_OK;
+}
+
+int rt_ctx_destroy(RtCtx* ctx) {
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& pl : ctx->pool) for (auto& b : pl) b.release();
+    ctx->blocksum.release(); ctx->counters.release(); ctx->out_tmp.release();
+    for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    if (ctx->h_count) (void)hipHostFree(ctx->h_count);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
+    if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
+    if (!desc || !out_scene) return set_err(ctx, RT_ERR_INVALID, "desc / out_scene is null");
+    *out_scene = nullptr;
+    rtc::CompiledScene cs;
+    const int rc = rtc::compile_scene(*desc, cs);
+    if (rc != RT_OK) return set_err(ctx, rc, "scene: " + cs.error);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RtScene* s = new RtScene();
+    int r = RT_OK;
+    auto up = [&](auto& buf, const auto& vec) { if (r == RT_OK) r = upload(ctx, buf, vec); };
+    up(s->nodes, cs.nodes); up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
+    up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->media, cs.media);
+    up(s->xforms, cs.xforms); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
+    up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
+    if (r == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = set_err(ctx, RT_ERR_DEVICE, "scene upload failed");
+    if (r != RT_OK) { rt_scene_destroy(ctx, s); return r; }
+    rtk::SceneDev& d = s->dev;
+    d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
+    d.spheres = (const rtd::Float4*)s->spheres.p; d.sphere_meta = (const uint32_t*)s->sphere_meta.p; d.n_spheres = (uint32_t)cs.spheres.size();
+    d.moving = (const rtd::Float4*)s->moving.p; d.moving_meta = (const uint32_t*)s->moving_meta.p;
+    d.rects = (const rtd::Float4*)s->rects.p; d.rect_meta = (const uint32_t*)s->rect_meta.p;
+    d.tris = (const rtd::Float4*)s->tris.p; d.tri_meta = (const uint32_t*)s->tri_meta.p;
+    d.media = (const rtd::Medium*)s->media.p; d.xforms = (const rtd::Xform*)s->xforms.p;
+    d.mat_a = (const rtd::Float4*)s->mat_a.p; d.mat_b = (const uint32_t*)s->mat_b.p;
+    d.textures = (const rtd::Texture*)s->textures.p; d.perlins = (const rtd::PerlinTable*)s->perlins.p;
+    d.images = (const rtd::Image*)s->images.p; d.image_bytes = (const uint8_t*)s->image_bytes.p;
+    d.lights = (const rtd::Light*)s->lights.p; d.n_lights = (uint32_t)cs.lights.size();
+    uint32_t f = 0;
+    if (!cs.moving_meta.empty()) f |= rtk::F_MOVING;
+    if (!cs.rect_meta.empty()) f |= rtk::F_RECT;
+    if (!cs.tri_meta.empty()) f |= rtk::F_TRI;
+    if (!cs.media.empty()) f |= rtk::F_MEDIUM;
+    if (cs.xforms.size() > 1) f |= rtk::F_XFORM;
+    for (uint32_t mb : cs.mat_b) { const uint32_t kind = mb & 15u; if ((mb >> 4) != rtd::TEX_INLINE && kind != rtd::MK_METAL && kind != rtd::MK_DIELECTRIC) f |= rtk::F_TEX; }
+    if (cs.has_lights) f |= rtk::F_LIGHTS;
+    s->features = f;
+    const size_t lds_bytes = cs.nodes.size() * 32 + cs.spheres.size() * 16;
+    s->in_lds = lds_bytes <= 64 * 1024;
+    s->bg_mode = cs.background_mode; for (int i = 0; i < 3; ++i) s->bg[i] = cs.background[i];
+    s->n_nodes = cs.nodes.size();
+    s->n_prims = cs.sphere_meta.size() + cs.moving_meta.size() + cs.rect_meta.size() + cs.tri_meta.size() + cs.media.size();
+    s->bytes = cs.nodes.size() * 32 + cs.spheres.size() * 16 + cs.moving.size() * 16 + cs.rects.size() * 16 + cs.tris.size() * 16 +
+               4 * (cs.sphere_meta.size() + cs.moving_meta.size() + cs.rect_meta.size() + cs.tri_meta.size());
+    *out_scene = s;
+    return RT_OK;
+}
+
+int rt_scene_destroy(RtCtx* ctx, RtScene* s) {
+    if (!s) return RT_OK;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    DevBuf* all[] = {&s->nodes, &s->spheres, &s->sphere_meta, &s->moving, &s->moving_meta, &s->rects, &s->rect_meta, &s->tris, &s->tri_meta, &s->media,
+                     &s->xforms, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights};
+    for (DevBuf* b : all) b->release();
+    delete s;
+    return RT_OK;
+}
+
+int rt_output_floats(const RtParams* p, uint64_t* out_n) {
+    if (!p || !out_n) return set_err(nullptr, RT_ERR_INVALID, "null argument");
+    Tiling t;
+    if (make_tiling(*p, t) != RT_OK) return set_err(nullptr, RT_ERR_INVALID, "bad tiling parameters");
+    if (p->shard_count <= 1u) *out_n = (uint64_t)p->width * p->height * 3u;
+    else *out_n = (uint64_t)t.n_local * t.ts * t.ts * 3u;
+    return RT_OK;
+}
+
+static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, void* d_out, RtStats* stats) {
+    using clk = std::chrono::steady_clock;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Tiling tl; make_tiling(*prm, tl);
+    const uint32_t sc = prm->shard_count <= 1u ? 1u : prm->shard_count, si = prm->shard_count <= 1u ? 0u : prm->shard_index;
+    rtk::RenderDev rd{};
+    auto cp3 = [](float* d, const RtVec3& v) { d[0] = (float)v.x; d[1] = (float)v.y; d[2] = (float)v.z; };
+    cp3(rd.cam_origin, cam->origin); cp3(rd.cam_llc, cam->lower_left_corner); cp3(rd.cam_horizontal, cam->horizontal); cp3(rd.cam_vertical, cam->vertical);
+    cp3(rd.cam_u, cam->u); cp3(rd.cam_v, cam->v);
+    rd.cam_lens_radius = (float)cam->lens_radius; rd.cam_time0 = (float)cam->time0; rd.cam_time1 = (float)cam->time1;
+    rd.width = prm->width; rd.height = prm->height; rd.spp = prm->samples_per_pixel; rd.max_depth = prm->max_depth; rd.seed = prm->seed;
+    rd.nan_policy = prm->nan_policy; rd.bg_mode = scene->bg_mode; for (int i = 0; i < 3; ++i) rd.bg[i] = scene->bg[i];
+    rd.tile_size = tl.ts; rd.tiles_x = tl.tiles_x; rd.tiles_y = tl.tiles_y; rd.shard_index = si; rd.shard_count = sc;
+    // samples per work item: as small as keeps the item count in 31 bits
+    uint32_t block_len = std::min<uint32_t>(16u, rd.spp);
+    const uint64_t ts2 = (uint64_t)tl.ts * tl.ts;
+    for (;;) {
+        const uint64_t nb = (rd.spp + block_len - 1) / block_len;
+        if ((uint64_t)tl.n_local * nb * ts2 < (1ull << 31) || block_len >= rd.spp) break;
+        block_len *= 2;
+    }
+    rd.block_len = block_len; rd.n_blocks = (rd.spp + block_len - 1) / block_len;
+    const uint64_t total_items = (uint64_t)tl.n_local * rd.n_blocks * ts2;
+    if (total_items >= (1ull << 32)) return set_err(ctx, RT_ERR_INVALID, "too many work items for one shard (image too large)");
+    rd.total_items = (uint32_t)total_items;
+
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); }
+    const auto t_begin = clk::now();
+    if (total_items == 0) { if (stats) stats->render_ms = 0.0; return RT_OK; }
+
+    uint32_t P = prm->pool_slots ? prm->pool_slots : (1u << 21);
+    P = (uint32_t)std::min<uint64_t>(P, total_items);
+    P = std::max<uint32_t>(256u, (P + 255u) & ~255u);
+    static const size_t rec[7] = {16, 16, 8, 16, 16, 16, 16};
+    rtk::PoolDev pd[2];
+    for (int k = 0; k < 2; ++k) {
+        for (int a = 0; a < 7; ++a) HIP_TRY(ctx, ctx->pool[k][a].ensure((size_t)P * rec[a]));
+        pd[k].ray_o = (rtd::Float4*)ctx->pool[k][0].p; pd[k].ray_d = (rtd::Float4*)ctx->pool[k][1].p; pd[k].hit = (uint2*)ctx->pool[k][2].p;
+        pd[k].s0 = (rtd::Float4*)ctx->pool[k][3].p; pd[k].s1 = (rtd::Float4*)ctx->pool[k][4].p; pd[k].s2 = (rtd::Float4*)ctx->pool[k][5].p;
+        pd[k].s3 = (rtd::Float4*)ctx->pool[k][6].p;
+    }
+    HIP_TRY(ctx, ctx->blocksum.ensure((size_t)total_items * 16));
+    rd.blocksum = (rtd::Float4*)ctx->blocksum.p;
+    // counters: [0] next_work, [1] head, [2],[3] pool counts; 64-bit stats from byte 64
+    HIP_TRY(ctx, ctx->counters.ensure(64 + sizeof(unsigned long long) * 16));
+    uint32_t* c32 = (uint32_t*)ctx->counters.p;
+    unsigned long long* c64 = (unsigned long long*)((char*)ctx->counters.p + 64);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, 64 + sizeof(unsigned long long) * 16, ctx->stream));
+
+    const bool counting = (prm->flags & RT_FLAG_COUNTERS) != 0, timing = (prm->flags & RT_FLAG_TIMING) != 0;
+    rtk::LaunchCfg cfg{};
+    cfg.extend_blocks = (uint32_t)ctx->n_cu * 8u; cfg.features = scene->features; cfg.scene_in_lds = scene->in_lds;
+
+    size_t ev_used = 0;
+    auto next_event = [&](hipEvent_t& ev) -> hipError_t {
+        if (ev_used == ctx->events.size()) { hipEvent_t e; hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return r; ctx->events.push_back(e); }
+        ev = ctx->events[ev_used++];
+        return hipEventRecord(ev, ctx->stream);
+    };
+    struct Span { hipEvent_t a, b; int kind; };
+    std::vector<Span> spans;
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) HIP_TRY(ctx, next_event(e0));
+    HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, P, &c32[0], &c32[2], ctx->stream));
+    if (timing) { HIP_TRY(ctx, next_event(e1)); spans.push_back({e0, e1, 2}); }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count, &c32[2], 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t live = ctx->h_count[0];
+    int cur = 0;
+    uint32_t iterations = 0; uint64_t segments = 0;
+    while (live > 0) {
+        HIP_TRY(ctx, hipMemsetAsync(&c32[1], 0, 4, ctx->stream));              // queue head
+        HIP_TRY(ctx, hipMemsetAsync(&c32[2 + (1 - cur)], 0, 4, ctx->stream));  // output count
+        hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
+        if (timing) HIP_TRY(ctx, next_event(ea));
+        HIP_TRY(ctx, rtk::launch_extend(cfg, scene->dev, pd[cur], rd, &c32[2 + cur], &c32[1], c64, counting, ctx->stream));
+        if (timing) HIP_TRY(ctx, next_event(eb));
+        HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, &c32[2 + cur], &c32[2 + (1 - cur)], &c32[0], c64, counting, ctx->stream));
+        if (timing) { HIP_TRY(ctx, next_event(ec)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); }
+        segments += live;
+        cur = 1 - cur;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count, &c32[2 + cur], 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        live = ctx->h_count[0];
+        ++iterations;
+        if (iterations > 100000000u) return set_err(ctx, RT_ERR_DEVICE, "render loop did not terminate");
+    }
+    hipEvent_t r0 = nullptr, r1 = nullptr;
+    if (timing) HIP_TRY(ctx, next_event(r0));
+    HIP_TRY(ctx, rtk::launch_resolve(rd, (float*)d_out, tl.n_local, ctx->stream));
+    if (timing) { HIP_TRY(ctx, next_event(r1)); spans.push_back({r0, r1, 2}); }
+    if (counting) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, c64, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        stats->render_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
+        for (const Span& s : spans) {
+            float ms = 0.f; if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) continue;
+            if (s.kind == 0) stats->extend_ms += ms; else if (s.kind == 1) stats->shade_ms += ms; else stats->other_ms += ms;
+        }
+        uint64_t valid_pixels = 0;
+        for (uint32_t lt = 0; lt < tl.n_local; ++lt) {
+            const uint32_t tile = si + lt * sc, tx = tile % tl.tiles_x, ty = tile / tl.tiles_x;
+            const uint32_t w = std::min(tl.ts, prm->width - tx * tl.ts), h = std::min(tl.ts, prm->height - ty * tl.ts);
+            valid_pixels += (uint64_t)w * h;
+        }
+        stats->samples = valid_pixels * rd.spp;
+        stats->segments = segments;
+        if (counting) {
+            stats->node_tests = ctx->h_counters[rtk::CTR_NODE_TESTS];
+            for (int k = 0; k < RT_N_PRIM_TYPES; ++k) stats->prim_tests[k] = ctx->h_counters[rtk::CTR_PRIM_TESTS + k];
+        }
+        stats->iterations = iterations; stats->extend_launches = iterations; stats->shade_launches = iterations; stats->pool_slots = P;
+        stats->scene_nodes = scene->n_nodes; stats->scene_prims = scene->n_prims; stats->scene_bytes = scene->bytes; stats->bvh_in_lds = scene->in_lds ? 1u : 0u;
+    }
+    return RT_OK;
+}
+
+int rt_render_device(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, void* rgb_sum_device, RtStats* stats) {
+    if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
+    if (!scene || !cam || !rgb_sum_device) return set_err(ctx, RT_ERR_INVALID, "scene / cam / output is null");
+    const int v = validate_params(ctx, prm); if (v != RT_OK) return v;
+    return render_impl(ctx, scene, cam, prm, rgb_sum_device, stats);
+}
+
+int rt_render(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, float* rgb_sum_host, RtStats* stats) {
+    if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
+    if (!scene || !cam || !rgb_sum_host) return set_err(ctx, RT_ERR_INVALID, "scene / cam / output is null");
+    const int v = validate_params(ctx, prm); if (v != RT_OK) return v;
+    uint64_t n = 0; rt_output_floats(prm, &n);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ctx->out_tmp.ensure(n * sizeof(float)));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int r = render_impl(ctx, scene, cam, prm, ctx->out_tmp.p, stats);
+    if (r != RT_OK) return r;
+    HIP_TRY(ctx, hipMemcpyAsync(rgb_sum_host, ctx->out_tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_untile(const RtParams* p, const float* gathered, float* rgb_sum) {
+    if (!p || !gathered || !rgb_sum) return set_err(nullptr, RT_ERR_INVALID, "null argument");
+    Tiling t; RtParams q = *p; q.shard_count = 1; q.shard_index = 0;
+    if (make_tiling(q, t) != RT_OK) return set_err(nullptr, RT_ERR_INVALID, "bad tiling parameters");
+    const uint32_t sc = p->shard_count <= 1u ? 1u : p->shard_count;
+    const uint64_t ts2 = (uint64_t)t.ts * t.ts;
+    // every shard buffer has the size of the largest shard (shard 0)
+    const uint64_t per_shard = (uint64_t)((t.n_tiles + sc - 1) / sc) * ts2 * 3u;
+    for (uint32_t tile = 0; tile < t.n_tiles; ++tile) {
+        const uint32_t s = tile % sc, lt = tile / sc, tx = tile % t.tiles_x, ty = tile / t.tiles_x;
+        const float* src = gathered + (uint64_t)s * per_shard + (uint64_t)lt * ts2 * 3u;
+        for (uint32_t py = 0; py < t.ts; ++py) {
+            const uint32_t y = ty * t.ts + py; if (y >= p->height) break;
+            for (uint32_t px = 0; px < t.ts; ++px) {
+                const uint32_t x = tx * t.ts + px; if (x >= p->width) break;
+                const float* a = src + ((uint64_t)py * t.ts + px) * 3u;
+                float* b = rgb_sum + ((uint64_t)y * p->width + x) * 3u;
+                b[0] = a[0]; b[1] = a[1]; b[2] = a[2];
+            }
+        }
+    }
+    return RT_OK;
+}
+
+int rt_resolve_device(RtCtx* ctx, const void* rgb_sum_device, uint32_t width, uint32_t height, uint32_t spp, void* rgb8_device) {
+    if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
+    if (!rgb_sum_device || !rgb8_device || spp == 0) return set_err(ctx, RT_ERR_INVALID, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, rtk::launch_write_color((const float*)rgb_sum_device, width * height, spp, (uint8_t*)rgb8_device, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,494 @@
+// scene_compile.cpp — compiles the reference-shaped object graph (RtSceneDesc) into the flat device
+// layout: a threaded (stackless) BVH in the reference's own visiting order plus per-type primitive
+// arrays.  Host-only code.
+//
+// BVH construction restates the INTENT of BVHNode::construct (bvh.rs:77-130): random axis per node
+// (bvh.rs:87), stable sort of the node's own sub-range by box minimum on that axis (bvh.rs:108 sorts
+// the whole vector by mistake — SURVEY F6), median split (bvh.rs:109), ordered pair for span 2
+// (bvh.rs:100-107), single object for span 1 (bvh.rs:96-98, tested once here instead of twice).
+#include "scene_compile.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <map>
+
+namespace rtc {
+namespace {
+
+constexpr double PI = 3.14159265358979323846264338327950288;
+constexpr uint64_t GAMMA = 0x9E3779B97F4A7C15ull;
+inline uint64_t fin(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct Box3 { double mn[3], mx[3]; };
+inline Box3 surrounding(const Box3& a, const Box3& b) {   // aabb.rs:57-69
+    Box3 o;
+    for (int i = 0; i < 3; ++i) { o.mn[i] = std::min(a.mn[i], b.mn[i]); o.mx[i] = std::max(a.mx[i], b.mx[i]); }
+    return o;
+}
+
+// world -> local map of a chain of Translate / RotateY wrappers: local = M(theta)(world - off),
+// M(theta)(x,z) = (cos*x - sin*z, sin*x + cos*z)  (hittable.rs:151-155)
+struct Chain {
+    double theta = 0.0;            // radians, sum of the RotateY angles
+    double off[3] = {0, 0, 0};
+    bool identity = true;
+    std::vector<char> ops;         // outer -> inner: 'W' translate/rotate, 'F' flip-face
+    uint32_t xform_id = 0;         // id of (theta, off) in CompiledScene::xforms
+};
+
+inline uint32_t fold_ff_mode(const std::vector<char>& ops) {
+    // inner -> outer: W forces front_face = true (hittable.rs:82-83,173), F negates it (hittable.rs:199)
+    int mode = 0;   // 0 keep, 1 negate, 2 true, 3 false
+    for (auto it = ops.rbegin(); it != ops.rend(); ++it) {
+        if (*it == 'W') mode = 2;
+        else mode = (mode == 0) ? 1 : (mode == 1) ? 0 : (mode == 2) ? 3 : 2;
+    }
+    return (uint32_t)mode;
+}
+
+inline float f_down(double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; }
+inline float f_up(double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; }
+
+struct Compiler {
+    const RtSceneDesc& d;
+    CompiledScene& out;
+    std::map<std::pair<long long, std::pair<long long, std::pair<long long, long long>>>, uint32_t> xform_cache;
+
+    Compiler(const RtSceneDesc& desc, CompiledScene& o) : d(desc), out(o) {}
+
+    bool fail(const std::string& m) { if (out.error.empty()) out.error = m; return false; }
+    bool ok() const { return out.error.empty(); }
+    const RtHittable* H(int id) { if (id < 0 || (uint64_t)id >= d.n_hittables) { fail("hittable id out of range"); return nullptr; } return &d.hittables[id]; }
+
+    // ---- bounding boxes, as each bounding_box() of the reference computes them (f64) ----
+    bool bbox(int id, double t0, double t1, Box3& b, int depth = 0) {
+        const RtHittable* h = H(id); if (!h) return false;
+        if (depth > 128) return fail("graph too deep (cycle?)");
+        const double* p = h->p;
+        switch (h->kind) {
+        case RT_HIT_SPHERE: for (int i = 0; i < 3; ++i) { b.mn[i] = p[i] - p[3]; b.mx[i] = p[i] + p[3]; } return true;            // sphere.rs:66-73
+        case RT_HIT_MOVING_SPHERE: {                                                                                                   // moving_sphere.rs:67-78
+            Box3 b0, b1; const double r = p[8];
+            for (int i = 0; i < 3; ++i) {
+                const double c0 = p[i] + ((t0 - p[6]) / (p[7] - p[6])) * (p[3 + i] - p[i]);
+                const double c1 = p[i] + ((t1 - p[6]) / (p[7] - p[6])) * (p[3 + i] - p[i]);
+                b0.mn[i] = c0 - r; b0.mx[i] = c0 + r; b1.mn[i] = c1 - r; b1.mx[i] = c1 + r;
+            }
+            b = surrounding(b0, b1); return true;
+        }
+        case RT_HIT_XY_RECT: b = Box3{{p[0], p[2], p[4] - 0.0001}, {p[1], p[3], p[4] + 0.0001}}; return true;                       // aarect.rs:49-56
+        case RT_HIT_XZ_RECT: b = Box3{{p[0], p[4] - 0.0001, p[2]}, {p[1], p[4] + 0.0001, p[3]}}; return true;                       // aarect.rs:99-106
+        case RT_HIT_YZ_RECT: b = Box3{{p[4] - 0.0001, p[0], p[2]}, {p[4] + 0.0001, p[1], p[3]}}; return true;                       // aarect.rs:168-175
+        case RT_HIT_TRIANGLE:
+            for (int i = 0; i < 3; ++i) { b.mn[i] = std::min(p[i], std::min(p[3 + i], p[6 + i])) - 0.0001; b.mx[i] = std::max(p[i], std::max(p[3 + i], p[6 + i])) + 0.0001; }
+            return true;
+        case RT_HIT_BOX: for (int i = 0; i < 3; ++i) { b.mn[i] = p[i]; b.mx[i] = p[3 + i]; } return true;                             // boxes.rs:80-83
+        case RT_HIT_LIST: case RT_HIT_BVH: {                                                                                           // hittable_list.rs:52-72, bvh.rs:144-147
+            if (h->n_children <= 0) return false;
+            const double a0 = h->kind == RT_HIT_BVH ? p[0] : t0, a1 = h->kind == RT_HIT_BVH ? p[1] : t1;
+            for (int c = 0; c < h->n_children; ++c) {
+                if ((uint64_t)(h->first_child + c) >= d.n_children) return fail("children out of range");
+                Box3 cb; if (!bbox(d.children[h->first_child + c], a0, a1, cb, depth + 1)) return false;
+                b = c == 0 ? cb : surrounding(b, cb);
+            }
+            return true;
+        }
+        case RT_HIT_TRANSLATE: {                                                                                                       // hittable.rs:86-95
+            if (!bbox(h->first_child, t0, t1, b, depth + 1)) return false;
+            for (int i = 0; i < 3; ++i) { b.mn[i] += p[i]; b.mx[i] += p[i]; }
+            return true;
+        }
+        case RT_HIT_ROTATE_Y: {                                                                                                        // hittable.rs:107-144 (child box at times 0,1)
+            Box3 cb; if (!bbox(h->first_child, 0.0, 1.0, cb, depth + 1)) return false;
+            const double radians = p[0] * PI / 180.0, s = std::sin(radians), c = std::cos(radians);
+            const double inf = std::numeric_limits<double>::infinity();
+            for (int i = 0; i < 3; ++i) { b.mn[i] = inf; b.mx[i] = -inf; }
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 2; ++k) {
+                const double x = i * cb.mx[0] + (1 - i) * cb.mn[0], y = j * cb.mx[1] + (1 - j) * cb.mn[1], z = k * cb.mx[2] + (1 - k) * cb.mn[2];
+                const double t[3] = {c * x + s * z, y, -s * x + c * z};
+                for (int a = 0; a < 3; ++a) { b.mn[a] = std::min(b.mn[a], t[a]); b.mx[a] = std::max(b.mx[a], t[a]); }
+            }
+            return true;
+        }
+        case RT_HIT_FLIP_FACE: case RT_HIT_CONSTANT_MEDIUM: return bbox(h->first_child, t0, t1, b, depth + 1);                         // hittable.rs:202-204
+        default: return fail("unknown hittable kind");
+        }
+    }
+
+    // ---- transforms ----
+    uint32_t intern_xform(const Chain& c) {
+        if (c.identity) return 0;
+        auto q = [](double v) { return (long long)std::llround(v * 1048576.0); };
+        auto key = std::make_pair(q(c.theta), std::make_pair(q(c.off[0]), std::make_pair(q(c.off[1]), q(c.off[2]))));
+        auto it = xform_cache.find(key);
+        if (it != xform_cache.end()) return it->second;
+        rtd::Xform x{};
+        x.sin_t = (float)std::sin(c.theta); x.cos_t = (float)std::cos(c.theta);
+        for (int i = 0; i < 3; ++i) x.off[i] = (float)c.off[i];
+        out.xforms.push_back(x);
+        if (out.xforms.size() > 255) fail("more than 255 distinct instance transforms");
+        xform_cache[key] = (uint32_t)out.xforms.size() - 1;
+        return (uint32_t)out.xforms.size() - 1;
+    }
+    static void apply_translate(Chain& c, const double* off2) {
+        // local' = M(theta)(w - off) - off2 = M(theta)(w - off - M(-theta) off2)
+        const double s = std::sin(c.theta), k = std::cos(c.theta);
+        c.off[0] += k * off2[0] + s * off2[2];
+        c.off[1] += off2[1];
+        c.off[2] += -s * off2[0] + k * off2[2];
+        c.identity = false;
+    }
+    static void apply_rotate(Chain& c, double degrees) { c.theta += degrees * PI / 180.0; c.identity = false; }
+
+    // ---- primitives ----
+    uint32_t meta_for(const RtHittable& h, const Chain& c) {
+        if (h.material < 0 || (uint64_t)h.material >= d.n_materials) { fail("primitive without a valid material"); return 0; }
+        if ((uint32_t)h.material > rtd::META_MAT_MASK) { fail("too many materials"); return 0; }
+        return rtd::make_meta((uint32_t)h.material, fold_ff_mode(c.ops), c.xform_id);
+    }
+    void push_leaf_node(uint32_t type, uint32_t first, uint32_t count) {
+        if (first > rtd::LEAF_MAX_FIRST) { fail("too many primitives of one type"); return; }
+        rtd::Node n{};
+        n.mn[0] = n.mn[1] = n.mn[2] = -std::numeric_limits<float>::infinity();
+        n.mx[0] = n.mx[1] = n.mx[2] = std::numeric_limits<float>::infinity();
+        n.leaf = rtd::make_leaf(type, first, count);
+        n.skip = 0;   // patched: a no-box node never takes its skip edge
+        out.nodes.push_back(n);
+        out.nodes.back().skip = (uint32_t)out.nodes.size();
+    }
+    uint32_t add_rect(int kaxis, double a0, double a1, double b0, double b1, double k, uint32_t meta) {
+        out.rects.push_back(rtd::Float4{(float)a0, (float)a1, (float)b0, (float)b1});
+        out.rects.push_back(rtd::Float4{(float)k, (float)kaxis, 0.f, 0.f});
+        out.rect_meta.push_back(meta);
+        return (uint32_t)out.rect_meta.size() - 1;
+    }
+    // boxes.rs:17-74 — the six sides in the reference's order
+    uint32_t add_box_rects(const double* p, uint32_t meta) {
+        const double x0 = p[0], y0 = p[1], z0 = p[2], x1 = p[3], y1 = p[4], z1 = p[5];
+        const uint32_t first = add_rect(2, x0, x1, y0, y1, z1, meta);
+        add_rect(2, x0, x1, y0, y1, z0, meta);
+        add_rect(1, x0, x1, z0, z1, y1, meta);
+        add_rect(1, x0, x1, z0, z1, y0, meta);
+        add_rect(0, y0, y1, z0, z1, x1, meta);
+        add_rect(0, y0, y1, z0, z1, x0, meta);
+        return first;
+    }
+
+    // Strip wrappers above `id`, folding them into the chain. Returns the first non-wrapper id.
+    int unwrap(int id, Chain& c, int depth = 0) {
+        while (true) {
+            const RtHittable* h = H(id); if (!h) return -1;
+            if (++depth > 128) { fail("wrapper chain too deep"); return -1; }
+            if (h->kind == RT_HIT_TRANSLATE) { apply_translate(c, h->p); c.ops.push_back('W'); id = h->first_child; }
+            else if (h->kind == RT_HIT_ROTATE_Y) { apply_rotate(c, h->p[0]); c.ops.push_back('W'); id = h->first_child; }
+            else if (h->kind == RT_HIT_FLIP_FACE) { c.ops.push_back('F'); id = h->first_child; }
+            else return id;
+        }
+    }
+
+    void emit(int id, const Chain& ctx, int depth = 0) {
+        if (!ok()) return;
+        if (depth > 128) { fail("graph too deep (cycle?)"); return; }
+        const RtHittable* h0 = H(id); if (!h0) return;
+        if (h0->kind == RT_HIT_TRANSLATE || h0->kind == RT_HIT_ROTATE_Y || h0->kind == RT_HIT_FLIP_FACE) {
+            Chain c = ctx;
+            const int inner = unwrap(id, c); if (inner < 0) return;
+            c.xform_id = intern_xform(c);
+            if (c.xform_id != ctx.xform_id) {
+                push_leaf_node(rtd::LT_ENTER, c.xform_id, 0);
+                emit(inner, c, depth + 1);
+                push_leaf_node(rtd::LT_EXIT, ctx.xform_id, 0);
+            } else emit(inner, c, depth + 1);
+            return;
+        }
+        const RtHittable& h = *h0;
+        const double* p = h.p;
+        switch (h.kind) {
+        case RT_HIT_SPHERE:
+            out.spheres.push_back(rtd::Float4{(float)p[0], (float)p[1], (float)p[2], (float)p[3]});
+            out.sphere_meta.push_back(meta_for(h, ctx));
+            push_leaf_node(rtd::LT_SPHERE, (uint32_t)out.sphere_meta.size() - 1, 1);
+            break;
+        case RT_HIT_MOVING_SPHERE:
+            out.moving.push_back(rtd::Float4{(float)p[0], (float)p[1], (float)p[2], (float)p[8]});
+            out.moving.push_back(rtd::Float4{(float)p[3], (float)p[4], (float)p[5], (float)p[6]});
+            out.moving.push_back(rtd::Float4{(float)p[7], 0.f, 0.f, 0.f});
+            out.moving_meta.push_back(meta_for(h, ctx));
+            push_leaf_node(rtd::LT_MOVING, (uint32_t)out.moving_meta.size() - 1, 1);
+            break;
+        case RT_HIT_XY_RECT: case RT_HIT_XZ_RECT: case RT_HIT_YZ_RECT: {
+            const int kaxis = h.kind == RT_HIT_XY_RECT ? 2 : (h.kind == RT_HIT_XZ_RECT ? 1 : 0);
+            const uint32_t idx = add_rect(kaxis, p[0], p[1], p[2], p[3], p[4], meta_for(h, ctx));
+            push_leaf_node(rtd::LT_RECT, idx, 1);
+            break;
+        }
+        case RT_HIT_TRIANGLE:
+            out.tris.push_back(rtd::Float4{(float)p[0], (float)p[1], (float)p[2], 0.f});
+            out.tris.push_back(rtd::Float4{(float)p[3], (float)p[4], (float)p[5], 0.f});
+            out.tris.push_back(rtd::Float4{(float)p[6], (float)p[7], (float)p[8], 0.f});
+            out.tri_meta.push_back(meta_for(h, ctx));
+            push_leaf_node(rtd::LT_TRI, (uint32_t)out.tri_meta.size() - 1, 1);
+            break;
+        case RT_HIT_BOX: {
+            const uint32_t first = add_box_rects(p, meta_for(h, ctx));
+            push_leaf_node(rtd::LT_RECT, first, 6);
+            break;
+        }
+        case RT_HIT_LIST:
+            for (int c = 0; c < h.n_children; ++c) {
+                if ((uint64_t)(h.first_child + c) >= d.n_children) { fail("children out of range"); return; }
+                emit(d.children[h.first_child + c], ctx, depth + 1);
+            }
+            break;
+        case RT_HIT_BVH: emit_bvh(id, h, ctx, depth); break;
+        case RT_HIT_CONSTANT_MEDIUM: emit_medium(id, h, ctx); break;
+        default: fail("unknown hittable kind");
+        }
+    }
+
+    void emit_medium(int id, const RtHittable& h, const Chain& ctx) {
+        Chain c = ctx; c.ops.clear();
+        const int inner = unwrap(h.first_child, c); if (inner < 0) return;
+        const RtHittable* b = H(inner); if (!b) return;
+        rtd::Medium m{};
+        m.boundary_xform = intern_xform(c);
+        if (b->kind == RT_HIT_SPHERE) {
+            out.spheres.push_back(rtd::Float4{(float)b->p[0], (float)b->p[1], (float)b->p[2], (float)b->p[3]});
+            out.sphere_meta.push_back(0);
+            m.boundary_type = rtd::LT_SPHERE; m.boundary_first = (uint32_t)out.sphere_meta.size() - 1; m.boundary_count = 1;
+        } else if (b->kind == RT_HIT_BOX) {
+            m.boundary_type = rtd::LT_RECT; m.boundary_first = add_box_rects(b->p, 0); m.boundary_count = 6;
+        } else { out.error = "constant medium boundary must be a sphere or a box (optionally under Translate/RotateY)"; return; }
+        if (h.p[0] == 0.0) { fail("constant medium with zero density"); return; }
+        m.neg_inv_density = (float)(-1.0 / h.p[0]);   // constant_medium.rs:25
+        Chain none; none.xform_id = 0;
+        m.meta = meta_for(h, none);
+        m.medium_id = (uint32_t)id;
+        out.media.push_back(m);
+        push_leaf_node(rtd::LT_MEDIUM, (uint32_t)out.media.size() - 1, 1);
+    }
+
+    // ---- BVH ----
+    struct Build { std::vector<int> obj; std::vector<double> key[3]; std::vector<Box3> box; uint64_t axis_state; };
+
+    void emit_bvh(int id, const RtHittable& h, const Chain& ctx, int depth) {
+        const int n = h.n_children;
+        if (n <= 0) { fail("empty BVH"); return; }
+        Build B;
+        B.obj.resize(n); B.box.resize(n); for (int a = 0; a < 3; ++a) B.key[a].resize(n);
+        for (int c = 0; c < n; ++c) {
+            if ((uint64_t)(h.first_child + c) >= d.n_children) { fail("children out of range"); return; }
+            const int cid = d.children[h.first_child + c];
+            Box3 k0;
+            if (!bbox(cid, 0.0, 0.0, k0) || !bbox(cid, h.p[0], h.p[1], B.box[c])) { fail("No bounding box in BVHNode constructor."); return; }   // bvh.rs:19-21,123-127
+            B.obj[c] = cid;
+            for (int a = 0; a < 3; ++a) B.key[a][c] = k0.mn[a];
+        }
+        std::vector<int> order(n); for (int i = 0; i < n; ++i) order[i] = i;
+        B.axis_state = fin(d.bvh_seed + GAMMA * (uint64_t)(id + 1));
+        build_range(B, order, 0, (size_t)n, ctx, depth);
+    }
+
+    Box3 range_box(const Build& B, const std::vector<int>& order, size_t s, size_t e) {
+        Box3 b = B.box[order[s]];
+        for (size_t i = s + 1; i < e; ++i) b = surrounding(b, B.box[order[i]]);
+        return b;
+    }
+
+    // BVHNode::construct (bvh.rs:77-130) on the sub-range [start, end)
+    Box3 build_range(Build& B, std::vector<int>& order, size_t start, size_t end, const Chain& ctx, int depth) {
+        B.axis_state += GAMMA;
+        const int axis = (int)((uint32_t)(fin(B.axis_state) >> 32) % 3u);   // bvh.rs:87
+        const size_t span = end - start;
+        const uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.push_back(rtd::Node{});   // box node, filled below
+        out.n_box_nodes++;
+        Box3 box;
+        if (span == 1) {
+            emit(B.obj[order[start]], ctx, depth + 1);
+            box = B.box[order[start]];
+        } else if (span == 2) {
+            const int a = order[start], b = order[start + 1];
+            const bool less = B.key[axis][a] < B.key[axis][b];   // box_compare: strictly less, else "greater" (bvh.rs:24-31)
+            const int l = less ? a : b, r = less ? b : a;
+            emit(B.obj[l], ctx, depth + 1);
+            emit(B.obj[r], ctx, depth + 1);
+            box = surrounding(B.box[l], B.box[r]);
+        } else {
+            const std::vector<double>& key = B.key[axis];
+            std::stable_sort(order.begin() + start, order.begin() + end, [&key](int x, int y) { return key[x] < key[y]; });   // sort_by is stable
+            const size_t mid = start + span / 2;
+            const Box3 bl = build_range(B, order, start, mid, ctx, depth + 1);
+            const Box3 br = build_range(B, order, mid, end, ctx, depth + 1);
+            box = surrounding(bl, br);
+        }
+        rtd::Node& n = out.nodes[me];
+        // boxes live in the space the children are traversed in; children under an instance
+        // transform are traversed in local space, where the reference's boxes are defined too
+        for (int i = 0; i < 3; ++i) { n.mn[i] = f_down(box.mn[i]); n.mx[i] = f_up(box.mx[i]); }
+        n.leaf = 0;
+        n.skip = (uint32_t)out.nodes.size();
+        return box;
+    }
+
+    // ---- post passes: merge adjacent leaf runs; fold a box node and its single leaf run into one ----
+    static bool nobox(const rtd::Node& n) { return std::isinf(n.mn[0]) && n.mn[0] < 0; }
+    static uint32_t ltype(const rtd::Node& n) { return n.leaf >> 28; }
+    static uint32_t lcount(const rtd::Node& n) { return (n.leaf >> 24) & 15u; }
+    static uint32_t lfirst(const rtd::Node& n) { return n.leaf & rtd::LEAF_MAX_FIRST; }
+    static bool is_prim_run(const rtd::Node& n) { const uint32_t t = ltype(n); return n.leaf != 0 && t >= rtd::LT_SPHERE && t <= rtd::LT_TRI; }
+
+    void remap(std::vector<rtd::Node>& nodes, const std::vector<uint32_t>& map, uint32_t new_n) {
+        for (auto& n : nodes) n.skip = n.skip >= map.size() ? new_n : map[n.skip];
+    }
+
+    void merge_runs() {
+        std::vector<rtd::Node>& src = out.nodes;
+        const size_t n = src.size();
+        std::vector<char> target(n + 1, 0);
+        for (const auto& nd : src) if (!nobox(nd) && nd.skip <= n) target[nd.skip] = 1;
+        std::vector<rtd::Node> dst; dst.reserve(n);
+        std::vector<uint32_t> map(n + 1);
+        for (size_t i = 0; i < n; ++i) {
+            const rtd::Node& nd = src[i];
+            if (!dst.empty() && !target[i] && nobox(nd) && is_prim_run(nd)) {
+                rtd::Node& pv = dst.back();
+                if (nobox(pv) && is_prim_run(pv) && ltype(pv) == ltype(nd) && lfirst(pv) + lcount(pv) == lfirst(nd) &&
+                    lcount(pv) + lcount(nd) <= rtd::LEAF_MAX_COUNT) {
+                    pv.leaf = rtd::make_leaf(ltype(pv), lfirst(pv), lcount(pv) + lcount(nd));
+                    map[i] = (uint32_t)dst.size() - 1;
+                    continue;
+                }
+            }
+            map[i] = (uint32_t)dst.size();
+            dst.push_back(nd);
+        }
+        map[n] = (uint32_t)dst.size();
+        remap(dst, map, (uint32_t)dst.size());
+        for (size_t i = 0; i < dst.size(); ++i) if (nobox(dst[i])) dst[i].skip = (uint32_t)i + 1;
+        src.swap(dst);
+    }
+
+    void fold_box_leaf() {
+        std::vector<rtd::Node>& src = out.nodes;
+        const size_t n = src.size();
+        std::vector<rtd::Node> dst; dst.reserve(n);
+        std::vector<uint32_t> map(n + 1);
+        for (size_t i = 0; i < n; ++i) {
+            map[i] = (uint32_t)dst.size();
+            const rtd::Node& nd = src[i];
+            if (!nobox(nd) && nd.leaf == 0 && i + 1 < n && nd.skip == i + 2 && nobox(src[i + 1]) && is_prim_run(src[i + 1])) {
+                rtd::Node f = nd; f.leaf = src[i + 1].leaf;
+                dst.push_back(f);
+                map[i + 1] = (uint32_t)dst.size();   // nothing points at it; keep the map total
+                ++i;
+                continue;
+            }
+            dst.push_back(nd);
+        }
+        map[n] = (uint32_t)dst.size();
+        remap(dst, map, (uint32_t)dst.size());
+        for (size_t i = 0; i < dst.size(); ++i) if (nobox(dst[i])) dst[i].skip = (uint32_t)i + 1;
+        src.swap(dst);
+    }
+
+    // ---- materials, textures, lights ----
+    void compile_materials() {
+        for (uint64_t i = 0; i < d.n_textures; ++i) {
+            const RtTexture& t = d.textures[i];
+            rtd::Texture o{};
+            o.kind = (uint32_t)t.kind; o.a = t.a; o.b = t.b; o.scale = (float)t.scale;
+            o.color[0] = (float)t.color.x; o.color[1] = (float)t.color.y; o.color[2] = (float)t.color.z;
+            if (t.kind < RT_TEX_SOLID || t.kind > RT_TEX_IMAGE) { fail("unknown texture kind"); return; }
+            if (t.kind == RT_TEX_CHECKER && (t.a < 0 || t.b < 0 || (uint64_t)t.a >= d.n_textures || (uint64_t)t.b >= d.n_textures)) { fail("checker texture ids out of range"); return; }
+            if (t.kind == RT_TEX_NOISE && (t.a < 0 || (uint64_t)t.a >= d.n_perlins)) { fail("noise texture perlin id out of range"); return; }
+            if (t.kind == RT_TEX_IMAGE && (t.a >= 0 && (uint64_t)t.a >= d.n_images)) { fail("image id out of range"); return; }
+            out.textures.push_back(o);
+        }
+        for (uint64_t i = 0; i < d.n_perlins; ++i) {
+            rtd::PerlinTable pt{};
+            for (int k = 0; k < 256; ++k) {
+                pt.ranvec[k] = rtd::Float4{(float)d.perlins[i].ranvec[k][0], (float)d.perlins[i].ranvec[k][1], (float)d.perlins[i].ranvec[k][2], 0.f};
+                pt.perm_x[k] = d.perlins[i].perm_x[k] & 255u; pt.perm_y[k] = d.perlins[i].perm_y[k] & 255u; pt.perm_z[k] = d.perlins[i].perm_z[k] & 255u;
+            }
+            out.perlins.push_back(pt);
+        }
+        for (uint64_t i = 0; i < d.n_images; ++i) {
+            const RtImage& im = d.images[i];
+            rtd::Image o{}; o.offset = out.image_bytes.size(); o.width = im.data ? im.width : 0; o.height = im.data ? im.height : 0;
+            if (im.data) out.image_bytes.insert(out.image_bytes.end(), im.data, im.data + (size_t)im.width * im.height * 3);
+            out.images.push_back(o);
+        }
+        for (uint64_t i = 0; i < d.n_materials; ++i) {
+            const RtMaterial& m = d.materials[i];
+            rtd::Float4 a{0, 0, 0, 0}; uint32_t tex = rtd::TEX_INLINE;
+            switch (m.kind) {
+            case RT_MAT_LAMBERTIAN: case RT_MAT_DIFFUSE_LIGHT: case RT_MAT_ISOTROPIC: {
+                if (m.texture < 0 || (uint64_t)m.texture >= d.n_textures) { fail("material texture id out of range"); return; }
+                const RtTexture& t = d.textures[m.texture];
+                if (t.kind == RT_TEX_SOLID) a = rtd::Float4{(float)t.color.x, (float)t.color.y, (float)t.color.z, 0.f};
+                else tex = (uint32_t)m.texture;
+                break;
+            }
+            case RT_MAT_METAL: a = rtd::Float4{(float)m.albedo.x, (float)m.albedo.y, (float)m.albedo.z, (float)m.fuzz}; break;
+            case RT_MAT_DIELECTRIC: a = rtd::Float4{1.f, 1.f, 1.f, (float)m.ir}; break;
+            default: fail("unknown material kind"); return;
+            }
+            out.mat_a.push_back(a);
+            out.mat_b.push_back(rtd::make_mat_b((uint32_t)m.kind, tex));
+        }
+    }
+
+    void compile_lights() {
+        out.has_lights = d.lights >= 0;
+        if (!out.has_lights) return;
+        const RtHittable* L = H(d.lights); if (!L) return;
+        std::vector<int> ids;
+        if (L->kind == RT_HIT_LIST) {
+            for (int c = 0; c < L->n_children; ++c) {
+                if ((uint64_t)(L->first_child + c) >= d.n_children) { fail("children out of range"); return; }
+                ids.push_back(d.children[L->first_child + c]);
+            }
+        } else ids.push_back(d.lights);
+        if (ids.empty()) { fail("empty lights list (the reference divides by its length, hittable_list.rs:74,82)"); return; }
+        for (int id : ids) {
+            const RtHittable* h = H(id); if (!h) return;
+            rtd::Light l{};
+            if (h->kind == RT_HIT_XZ_RECT) { l.kind = rtd::LK_XZRECT; for (int i = 0; i < 5; ++i) l.p[i] = (float)h->p[i]; }
+            else if (h->kind == RT_HIT_SPHERE) { l.kind = rtd::LK_SPHERE; for (int i = 0; i < 4; ++i) l.p[i] = (float)h->p[i]; }
+            else l.kind = rtd::LK_DEFAULT;   // trait defaults: pdf_value = 0, random = (1,0,0)  (hittable.rs:54-59)
+            out.lights.push_back(l);
+        }
+    }
+};
+
+}  // namespace
+
+int compile_scene(const RtSceneDesc& desc, CompiledScene& out) {
+    out = CompiledScene();
+    if (desc.abi_version != RT_ABI_VERSION) { out.error = "RtSceneDesc.abi_version mismatch"; return RT_ERR_INVALID; }
+    if (!desc.hittables || desc.n_hittables == 0) { out.error = "scene has no hittables"; return RT_ERR_INVALID; }
+    if ((desc.n_children && !desc.children) || (desc.n_materials && !desc.materials) || (desc.n_textures && !desc.textures) ||
+        (desc.n_perlins && !desc.perlins) || (desc.n_images && !desc.images)) { out.error = "null array with non-zero count"; return RT_ERR_INVALID; }
+    Compiler c(desc, out);
+    out.xforms.push_back(rtd::Xform{0.f, 1.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
+    c.compile_materials();
+    if (!c.ok()) return RT_ERR_INVALID;
+    Chain root;
+    c.emit(desc.world, root);
+    if (!c.ok()) return out.error.find("must be") != std::string::npos ? RT_ERR_UNSUPPORTED : RT_ERR_INVALID;
+    c.merge_runs();
+    c.fold_box_leaf();
+    c.compile_lights();
+    if (!c.ok()) return RT_ERR_INVALID;
+    out.background_mode = desc.background_mode;
+    out.background[0] = (float)desc.background.x; out.background[1] = (float)desc.background.y; out.background[2] = (float)desc.background.z;
+    return RT_OK;
+}
+
+}  // namespace rtc

@@ -1,0 +1,82 @@
+// host_capi.cpp — C exports of the host mirror (include/rt_host.h). No GPU code.
+#include "../../include/rt_host.h"
+#include "rt_host.hpp"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct RtHostScene {
+    rt::SceneRecipe recipe;
+    rt::FlatScene flat;
+};
+
+extern "C" {
+
+int rt_host_scene_create(const char* name, uint64_t scene_seed, uint64_t arg0, uint64_t arg1, const uint8_t* image, uint32_t image_w, uint32_t image_h,
+                         RtHostScene** out) {
+    if (!name || !out) return RT_ERR_INVALID;
+    *out = nullptr;
+    const std::string n(name);
+    auto* s = new RtHostScene();
+    if (n == "book1") s->recipe = rt::random_scene(scene_seed, 0, true);
+    else if (n == "book1_list") s->recipe = rt::random_scene(scene_seed, 0, false);
+    else if (n == "book1_ref") s->recipe = rt::random_scene(scene_seed, 1, true);
+    else if (n == "cornell") s->recipe = rt::cornell_box();
+    else if (n == "cornell_smoke") s->recipe = rt::cornell_smoke();
+    else if (n == "final") s->recipe = rt::final_scene(scene_seed, image, image_w, image_h);
+    else if (n == "big") s->recipe = rt::big_scene(scene_seed, (uint32_t)arg0, (uint32_t)arg1);
+    else { delete s; return RT_ERR_INVALID; }
+    s->flat.finish(s->recipe.world, s->recipe.lights, s->recipe.background_mode, s->recipe.background, rt::SceneRng::fin(scene_seed ^ 0xB5AD4ECEDA1CE2A9ull));
+    *out = s;
+    return RT_OK;
+}
+const RtSceneDesc* rt_host_scene_desc(const RtHostScene* s) { return s ? &s->flat.desc : nullptr; }
+int rt_host_scene_camera(const RtHostScene* s, double aspect_ratio, RtCamera* out) {
+    if (!s || !out) return RT_ERR_INVALID;
+    *out = s->recipe.camera(aspect_ratio).abi();
+    return RT_OK;
+}
+void rt_host_scene_destroy(RtHostScene* s) { delete s; }
+
+void rt_host_camera_new(const double* lf, const double* la, const double* up, const double* scope4, double time0, double time1, RtCamera* out) {
+    *out = rt::Camera::construct(rt::Point3(lf[0], lf[1], lf[2]), rt::Point3(la[0], la[1], la[2]), rt::Vec3(up[0], up[1], up[2]), scope4, time0, time1).abi();
+}
+void rt_host_write_color(const double* c, uint32_t spp, uint8_t* out3) { rt::write_color(c, spp, out3); }
+int rt_host_tonemap(const float* rgb_sum, uint32_t w, uint32_t h, uint32_t spp, uint8_t* rgb8) {
+    if (!rgb_sum || !rgb8 || spp == 0) return RT_ERR_INVALID;
+    const size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; ++i) { const double c[3] = {rgb_sum[3 * i], rgb_sum[3 * i + 1], rgb_sum[3 * i + 2]}; rt::write_color(c, spp, rgb8 + 3 * i); }
+    return RT_OK;
+}
+
+static void put32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+static void chunk(std::vector<uint8_t>& png, const char* type, const std::vector<uint8_t>& data) {
+    put32(png, (uint32_t)data.size());
+    const size_t at = png.size();
+    png.insert(png.end(), type, type + 4);
+    png.insert(png.end(), data.begin(), data.end());
+    put32(png, (uint32_t)crc32(0L, png.data() + at, (uInt)(png.size() - at)));
+}
+int rt_host_write_png(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h) {
+    if (!path || !rgb8 || !w || !h) return -1;
+    std::vector<uint8_t> raw; raw.reserve((size_t)h * (3 * (size_t)w + 1));
+    for (uint32_t y = 0; y < h; ++y) { raw.push_back(0); raw.insert(raw.end(), rgb8 + (size_t)y * w * 3, rgb8 + (size_t)(y + 1) * w * 3); }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return -1;
+    z.resize(zlen);
+    std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr; put32(ihdr, w); put32(ihdr, h); ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk(png, "IHDR", ihdr); chunk(png, "IDAT", z); chunk(png, "IEND", {});
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return -1;
+    const size_t wr = std::fwrite(png.data(), 1, png.size(), f);
+    std::fclose(f);
+    return wr == png.size() ? 0 : -1;
+}
+
+}  // extern "C"

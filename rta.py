@@ -1,0 +1,21 @@
+"""Loader for the package in ``ray-tracer-archive_amd/`` (the hyphen keeps it from being imported by name).
+
+    import rta
+    pkg = rta.load()          # module ``ray_tracer_archive_amd``
+"""
+import importlib.util
+import os
+import sys
+
+_NAME = "ray_tracer_archive_amd"
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ray-tracer-archive_amd")
+
+
+def load():
+    if _NAME in sys.modules:
+        return sys.modules[_NAME]
+    spec = importlib.util.spec_from_file_location(_NAME, os.path.join(_DIR, "__init__.py"), submodule_search_locations=[_DIR])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[_NAME] = mod
+    spec.loader.exec_module(mod)
+    return mod
