@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s (pixels x spp / s) of the path-tracing hot path on the book-1 final scene.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one full render of the workload (BASELINE.json configs[1]: book-1 random spheres,
+1200x800, 500 spp, depth 50) through the C ABI, output left in HBM. With N GPUs the framebuffer is
+tile-sharded (one process per GPU) and gathered on rank 0 with one RCCL gather; per-GPU work is
+held fixed (weak scaling: the image grows to N x 960k pixels at the same aspect and view).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+NODE_BYTES, SPHERE_BYTES, RAY_BYTES, HIT_BYTES = 32, 20, 32, 8   # SURVEY.md §8(d) record sizes
+
+
+def image_size(n_gpus, base_w=1200, base_h=800):
+    """Same 3:2 view, N x the pixels (weak scaling)."""
+    if n_gpus == 1:
+        return base_w, base_h
+    s = math.sqrt(n_gpus)
+    return int(round(base_w * s / 8)) * 8, int(round(base_h * s / 8)) * 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=500)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
+    ap.add_argument("--pool-slots", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import rta
+    pkg = rta.load()
+    A = pkg._abi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+    n_gpus = max(world, 1)
+    if args.gpus != n_gpus and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ctx = pkg.Context(local_rank, stream.cuda_stream)   # kernels go on torch's current stream
+    hs = pkg.HostScene("book1", 1)
+    scene = ctx.upload(hs.desc)
+    W, H = (args.width, args.height) if args.width and args.height else image_size(n_gpus)
+    cam = hs.camera(W / H)
+    base = pkg.make_params(W, H, args.spp, max_depth=50, seed=1, flags=A.RT_FLAG_TIMING, pool_slots=args.pool_slots)
+    from importlib import import_module
+    D = import_module("ray_tracer_archive_amd.distributed")
+
+    stats_acc = []
+
+    def render_shard(prm, out):
+        stats_acc.append(ctx.render_device(scene, cam, prm, out.data_ptr()))
+
+    def step():
+        return D.render_sharded(render_shard, base, rank, n_gpus, dist, device=dev)
+
+    for _ in range(args.warmup):
+        step()
+    stats_acc.clear()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-rank device statistics of the timed steps
+    seg = sum(s["segments"] for s in stats_acc)
+    ext_ms = sum(s["extend_ms"] for s in stats_acc)
+    shade_ms = sum(s["shade_ms"] for s in stats_acc)
+    launches = sum(s["extend_launches"] for s in stats_acc)
+    samples_rank = sum(s["samples"] for s in stats_acc)
+    if dist is not None:
+        t = torch.tensor([samples_rank], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        samples_total = float(t.item())
+    else:
+        samples_total = float(samples_rank)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    value = samples_total / dt / 1e6
+    out = {
+        "metric": "Msamples/s (pixels x spp / s), book-1 final scene", "value": round(value, 3), "unit": "Msamples/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"book-1 final random-spheres scene (scene_seed 1, 484 spheres, reference-shaped BVH), {W}x{H}, {args.spp} spp, "
+                               f"depth 50, seed 1; output rgb_sum left in HBM" + (f"; {n_gpus} ranks, 32x32 tiles round-robin, one RCCL gather" if n_gpus > 1 else ""),
+                   "width": W, "height": H, "spp": args.spp, "max_depth": 50, "pool_slots": stats_acc[0]["pool_slots"] if stats_acc else 0,
+                   "bvh_in_lds": stats_acc[0]["bvh_in_lds"] if stats_acc else 0},
+    }
+
+    # ---- roofline of the dominant kernel (k_extend = BVH traversal), rank 0's launches ----
+    # algorithmic bytes per ray segment = V_n*32 + V_p*20 (node and sphere records the reference
+    # algorithm touches, counted on the device in a separate counting pass of the same workload at
+    # 1/10 spp) + 32 (ray read) + 8 (hit write).
+    cprm = pkg.make_params(W, H, max(1, args.spp // 10), max_depth=50, seed=1, flags=A.RT_FLAG_COUNTERS,
+                           tile_size=32 if n_gpus > 1 else 0, shard_index=0, shard_count=n_gpus)
+    tmp = torch.zeros(pkg.output_floats(cprm), dtype=torch.float32, device=dev)
+    cst = ctx.render_device(scene, cam, cprm, tmp.data_ptr())
+    vn = cst["node_tests"] / max(1, cst["segments"])
+    vp = cst["prim_tests"][0] / max(1, cst["segments"])
+    seg_per_sample = cst["segments"] / max(1, cst["samples"])
+    b_seg_trav = vn * NODE_BYTES + vp * SPHERE_BYTES
+    b_seg = b_seg_trav + RAY_BYTES + HIT_BYTES
+    achieved = seg * b_seg / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+    out["roofline"] = {
+        "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "avg_launch_ms": round(ext_ms / max(1, launches), 4), "launches": launches, "segments_per_launch": round(seg / max(1, launches), 1),
+        "bytes_per_segment": round(b_seg, 1), "node_tests_per_segment": round(vn, 2), "sphere_tests_per_segment": round(vp, 2),
+        "segments_per_sample": round(seg_per_sample, 3),
+        "note": "achieved = algorithmic bytes (reference-order traversal) / k_extend time from HIP events; the 24 KB scene is LDS-resident, "
+                "so HBM traffic proper is ray state only (see DESIGN.md)",
+        "extend_ms_per_step": round(ext_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
+        # whole-path figure in SURVEY 8(d)'s units: B_sample = sum over segments (V_n*32 + V_p*20 + 128) + 12
+        "whole_path": {"bytes_per_sample": round(seg_per_sample * (b_seg_trav + 128) + 12, 1),
+                       "achieved": round(value * 1e6 * (seg_per_sample * (b_seg_trav + 128) + 12) / 1e9 / n_gpus, 1),
+                       "frac": round(value * 1e6 * (seg_per_sample * (b_seg_trav + 128) + 12) / 1e9 / n_gpus / HBM_PEAK_GBS, 4)},
+    }
+
+    # ---- CPU baseline: the oracle (a port of the reference's CPU path), all host cores, bounded sample ----
+    if n_gpus == 1 and args.cpu_seconds > 0:
+        from oracle import binding as orc
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        bw, bh = 1200, 800
+        bcam = hs.camera(bw / bh)
+        probe = pkg.make_params(bw, bh, 1, max_depth=50, seed=1)
+        _, pst = orc.render(hs.desc, bcam, probe, precision=64, n_threads=cores)
+        rate = pst["samples"] / max(pst["seconds"], 1e-6)
+        spp_b = int(max(2, min(args.spp, args.cpu_seconds * rate / (bw * bh))))
+        bprm = pkg.make_params(bw, bh, spp_b, max_depth=50, seed=1)
+        _, bst = orc.render(hs.desc, bcam, bprm, precision=64, n_threads=cores)
+        out["cpu_baseline"] = {"value": round(bst["samples"] / bst["seconds"] / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                               "sample": f"same scene/camera/seed at {bw}x{bh}, {spp_b} spp ({bst['samples']} samples, {bst['seconds']:.1f} s), "
+                                         f"f64 oracle (oracle/oracle.cpp), std::thread over rows"}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

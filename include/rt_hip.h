@@ -225,6 +225,8 @@ int rt_output_floats(const RtParams* params, uint64_t* out_n);
        reference's j = height-1-y (main.rs:733);
      - sharded: this shard's tiles back to back, each tile_size*tile_size*3 floats row-major
        (pixels outside the image are 0); rt_untile() on the host puts gathered shards in place.
+       Shards may differ by one tile; a gather uses equal buffers of shard 0's size
+       (rt_output_floats with shard_index 0), which is what rt_untile expects.
    rt_render copies to a host buffer; rt_render_device leaves the result in device memory the
    caller owns (e.g. a torch tensor that RCCL then gathers). Both block until done. */
 int rt_render(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* params,
@@ -239,6 +241,20 @@ int rt_untile(const RtParams* params, const float* gathered, float* rgb_sum);
 /* write_color (main.rs:141-169) on the device: rgb_sum (device, full frame) -> RGB8 (device). */
 int rt_resolve_device(RtCtx* ctx, const void* rgb_sum_device, uint32_t width, uint32_t height,
                       uint32_t samples_per_pixel, void* rgb8_device);
+
+/* ---- introspection of the scene compiler: host only, never touches a GPU ---- */
+typedef struct RtCompileInfo {
+    uint64_t n_nodes;       /* threaded-BVH records */
+    uint64_t n_box_nodes;   /* of which carry a box (= BVHNode count of the reference tree) */
+    uint64_t n_spheres, n_moving, n_rects, n_tris, n_media, n_xforms, n_lights, n_materials;
+    uint32_t features;      /* kernel feature bits the scene needs */
+    uint32_t fits_lds;      /* nodes + sphere records fit the LDS staging budget */
+} RtCompileInfo;
+int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out);
+/* Copies the compiled node records (32 B each: f32 min[3], u32 skip, f32 max[3], u32 leaf) and the
+   sphere records (f32 center[3], radius) + per-sphere meta words. Any output pointer may be NULL. */
+int rt_scene_compile_dump(const RtSceneDesc* desc, void* nodes, uint64_t cap_nodes,
+                          float* spheres, uint32_t* sphere_meta, uint64_t cap_spheres);
 
 const char* rt_last_error(const RtCtx* ctx);  /* ctx may be NULL: last error of this thread */
 uint32_t rt_abi_version(void);

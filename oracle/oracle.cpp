@@ -1002,7 +1002,8 @@ static void write_color(const double* pixel_color, uint32_t samples_per_pixel, u
         if (c[i] != c[i]) c[i] = 0.0;
         double scale = 1.0 / (double)samples_per_pixel;
         c[i] = std::sqrt(scale * c[i]);
-        out[i] = (uint8_t)(256.0 * clamp(c[i], 0.0, 0.999));
+        const double q = 256.0 * clamp(c[i], 0.0, 0.999);
+        out[i] = q != q ? 0 : (uint8_t)q;   // Rust `as u8` saturates and maps NaN to 0
     }
 }
 

@@ -81,9 +81,16 @@ class RtStats(C.Structure):
         return d
 
 
+class RtCompileInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_box_nodes", C.c_uint64), ("n_spheres", C.c_uint64), ("n_moving", C.c_uint64), ("n_rects", C.c_uint64),
+                ("n_tris", C.c_uint64), ("n_media", C.c_uint64), ("n_xforms", C.c_uint64), ("n_lights", C.c_uint64), ("n_materials", C.c_uint64),
+                ("features", C.c_uint32), ("fits_lds", C.c_uint32)]
+
+
 # every symbol include/rt_hip.h and include/rt_host.h declare
 RT_HIP_SYMBOLS = ["rt_ctx_create", "rt_ctx_destroy", "rt_scene_upload", "rt_scene_destroy", "rt_output_floats", "rt_render",
-                  "rt_render_device", "rt_untile", "rt_resolve_device", "rt_last_error", "rt_abi_version"]
+                  "rt_render_device", "rt_untile", "rt_resolve_device", "rt_last_error", "rt_abi_version", "rt_scene_compile_info",
+                  "rt_scene_compile_dump"]
 RT_HOST_SYMBOLS = ["rt_host_scene_create", "rt_host_scene_desc", "rt_host_scene_camera", "rt_host_scene_destroy", "rt_host_camera_new",
                    "rt_host_write_color", "rt_host_tonemap", "rt_host_write_png"]
 
@@ -114,6 +121,10 @@ def declare(lib):
     lib.rt_untile.argtypes = [P(RtParams), P(C.c_float), P(C.c_float)]
     lib.rt_resolve_device.restype = i32
     lib.rt_resolve_device.argtypes = [vp, vp, u32, u32, u32, vp]
+    lib.rt_scene_compile_info.restype = i32
+    lib.rt_scene_compile_info.argtypes = [P(RtSceneDesc), P(RtCompileInfo)]
+    lib.rt_scene_compile_dump.restype = i32
+    lib.rt_scene_compile_dump.argtypes = [P(RtSceneDesc), vp, u64, P(C.c_float), P(u32), u64]
     lib.rt_host_scene_create.restype = i32
     lib.rt_host_scene_create.argtypes = [C.c_char_p, u64, u64, u64, P(C.c_uint8), u32, u32, P(vp)]
     lib.rt_host_scene_desc.restype = P(RtSceneDesc)

@@ -89,6 +89,26 @@ def untile(params, gathered):
     return out
 
 
+def compile_info(desc):
+    """rt_scene_compile_info: what the scene compiler makes of a graph (host only)."""
+    info = A.RtCompileInfo()
+    _check(lib().rt_scene_compile_info(C.byref(desc), C.byref(info)))
+    return {n: getattr(info, n) for n, _ in info._fields_}
+
+
+def compile_dump(desc):
+    """rt_scene_compile_dump: (nodes structured array, spheres (n,4) f32, sphere_meta u32)."""
+    info = compile_info(desc)
+    node_t = np.dtype([("mn", np.float32, 3), ("skip", np.uint32), ("mx", np.float32, 3), ("leaf", np.uint32)])
+    nodes = np.zeros(info["n_nodes"], dtype=node_t)
+    n_s = max(1, info["n_spheres"] + info["n_media"])   # media boundaries add private spheres
+    spheres = np.zeros((n_s, 4), dtype=np.float32)
+    meta = np.zeros(n_s, dtype=np.uint32)
+    _check(lib().rt_scene_compile_dump(C.byref(desc), nodes.ctypes.data_as(C.c_void_p), len(nodes), spheres.ctypes.data_as(C.POINTER(C.c_float)),
+                                       meta.ctypes.data_as(C.POINTER(C.c_uint32)), n_s))
+    return nodes, spheres[:info["n_spheres"]], meta[:info["n_spheres"]]
+
+
 class HostScene:
     """A scene function of main.rs, built by the C++ host mirror (host/rt_host.hpp)."""
 

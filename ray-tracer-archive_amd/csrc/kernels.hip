@@ -841,7 +841,8 @@ __global__ void __launch_bounds__(256) k_write_color(const float* __restrict__ r
     const float scale = 1.0f / (float)spp;
     c = sqrtf(scale * c);
     c = c < 0.f ? 0.f : (c > 0.999f ? 0.999f : c);
-    rgb8[i] = (uint8_t)(256.0f * c);
+    const float q = 256.0f * c;
+    rgb8[i] = q != q ? (uint8_t)0 : (uint8_t)q;   // Rust `as u8`: saturating, NaN -> 0
 }
 
 // ------------------------------------------------------------------------------------------------

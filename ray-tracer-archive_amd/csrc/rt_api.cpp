@@ -17,6 +17,7 @@
 namespace {
 
 thread_local std::string g_last_error;
+constexpr size_t kLdsSceneBudget = 64 * 1024;   // nodes + sphere records staged per workgroup
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
@@ -32,6 +33,8 @@ struct DevBuf {
 };
 
 }  // namespace
+
+static uint32_t scene_features(const rtc::CompiledScene& cs);
 
 struct RtCtx {
     int device = 0;
@@ -167,17 +170,10 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     d.textures = (const rtd::Texture*)s->textures.p; d.perlins = (const rtd::PerlinTable*)s->perlins.p;
     d.images = (const rtd::Image*)s->images.p; d.image_bytes = (const uint8_t*)s->image_bytes.p;
     d.lights = (const rtd::Light*)s->lights.p; d.n_lights = (uint32_t)cs.lights.size();
-    uint32_t f = 0;
-    if (!cs.moving_meta.empty()) f |= rtk::F_MOVING;
-    if (!cs.rect_meta.empty()) f |= rtk::F_RECT;
-    if (!cs.tri_meta.empty()) f |= rtk::F_TRI;
-    if (!cs.media.empty()) f |= rtk::F_MEDIUM;
-    if (cs.xforms.size() > 1) f |= rtk::F_XFORM;
-    for (uint32_t mb : cs.mat_b) { const uint32_t kind = mb & 15u; if ((mb >> 4) != rtd::TEX_INLINE && kind != rtd::MK_METAL && kind != rtd::MK_DIELECTRIC) f |= rtk::F_TEX; }
-    if (cs.has_lights) f |= rtk::F_LIGHTS;
+    const uint32_t f = scene_features(cs);
     s->features = f;
     const size_t lds_bytes = cs.nodes.size() * 32 + cs.spheres.size() * 16;
-    s->in_lds = lds_bytes <= 64 * 1024;
+    s->in_lds = lds_bytes <= kLdsSceneBudget;
     s->bg_mode = cs.background_mode; for (int i = 0; i < 3; ++i) s->bg[i] = cs.background[i];
     s->n_nodes = cs.nodes.size();
     s->n_prims = cs.sphere_meta.size() + cs.moving_meta.size() + cs.rect_meta.size() + cs.tri_meta.size() + cs.media.size();
@@ -368,6 +364,43 @@ int rt_untile(const RtParams* p, const float* gathered, float* rgb_sum) {
             }
         }
     }
+    return RT_OK;
+}
+
+static uint32_t scene_features(const rtc::CompiledScene& cs) {
+    uint32_t f = 0;
+    if (!cs.moving_meta.empty()) f |= rtk::F_MOVING;
+    if (!cs.rect_meta.empty()) f |= rtk::F_RECT;
+    if (!cs.tri_meta.empty()) f |= rtk::F_TRI;
+    if (!cs.media.empty()) f |= rtk::F_MEDIUM;
+    if (cs.xforms.size() > 1) f |= rtk::F_XFORM;
+    for (uint32_t mb : cs.mat_b) { const uint32_t kind = mb & 15u; if ((mb >> 4) != rtd::TEX_INLINE && kind != rtd::MK_METAL && kind != rtd::MK_DIELECTRIC) f |= rtk::F_TEX; }
+    if (cs.has_lights) f |= rtk::F_LIGHTS;
+    return f;
+}
+
+int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out) {
+    if (!desc || !out) return set_err(nullptr, RT_ERR_INVALID, "null argument");
+    rtc::CompiledScene cs;
+    const int rc = rtc::compile_scene(*desc, cs);
+    if (rc != RT_OK) return set_err(nullptr, rc, "scene: " + cs.error);
+    out->n_nodes = cs.nodes.size(); out->n_box_nodes = cs.n_box_nodes; out->n_spheres = cs.sphere_meta.size(); out->n_moving = cs.moving_meta.size();
+    out->n_rects = cs.rect_meta.size(); out->n_tris = cs.tri_meta.size(); out->n_media = cs.media.size(); out->n_xforms = cs.xforms.size();
+    out->n_lights = cs.lights.size(); out->n_materials = cs.mat_b.size();
+    out->features = scene_features(cs);
+    out->fits_lds = (cs.nodes.size() * 32 + cs.spheres.size() * 16) <= kLdsSceneBudget ? 1u : 0u;
+    return RT_OK;
+}
+
+int rt_scene_compile_dump(const RtSceneDesc* desc, void* nodes, uint64_t cap_nodes, float* spheres, uint32_t* sphere_meta, uint64_t cap_spheres) {
+    if (!desc) return set_err(nullptr, RT_ERR_INVALID, "null argument");
+    rtc::CompiledScene cs;
+    const int rc = rtc::compile_scene(*desc, cs);
+    if (rc != RT_OK) return set_err(nullptr, rc, "scene: " + cs.error);
+    if ((nodes && cap_nodes < cs.nodes.size()) || ((spheres || sphere_meta) && cap_spheres < cs.sphere_meta.size())) return set_err(nullptr, RT_ERR_INVALID, "capacity too small");
+    if (nodes) std::memcpy(nodes, cs.nodes.data(), cs.nodes.size() * sizeof(rtd::Node));
+    if (spheres) std::memcpy(spheres, cs.spheres.data(), cs.spheres.size() * sizeof(rtd::Float4));
+    if (sphere_meta) std::memcpy(sphere_meta, cs.sphere_meta.data(), cs.sphere_meta.size() * 4);
     return RT_OK;
 }
 

@@ -187,7 +187,8 @@ inline void write_color(const double pixel_color[3], uint32_t samples_per_pixel,
         const double scale = 1.0 / (double)samples_per_pixel;
         c = std::sqrt(scale * c);
         c = c < 0.0 ? 0.0 : (c > 0.999 ? 0.999 : c);           // rt_weekend::clamp
-        out[i] = (uint8_t)(256.0 * c);
+        const double q = 256.0 * c;
+        out[i] = q != q ? 0 : (uint8_t)q;                        // Rust `as u8`: saturating, NaN -> 0
     }
 }
 

@@ -1,0 +1,154 @@
+"""The scene compiler (graph -> threaded BVH), checked on the CPU against the oracle's object graph."""
+import numpy as np
+import pytest
+
+
+def traverse(nodes, spheres, o, d, tmin=0.001):
+    """Python walk of the dumped threaded BVH (spheres only): returns (t, sphere index, node visits)."""
+    i, n = 0, len(nodes)
+    best, hit, visits = np.inf, -1, 0
+    o, d = np.asarray(o, float), np.asarray(d, float)
+    a = d @ d
+    while i < n:
+        nd = nodes[i]
+        boxed = np.isfinite(nd["mn"][0])
+        ok = True
+        if boxed:
+            visits += 1
+            lo, hi = tmin, best
+            with np.errstate(divide="ignore", invalid="ignore"):
+                for ax in range(3):
+                    inv = 1.0 / d[ax]
+                    t0, t1 = (nd["mn"][ax] - o[ax]) * inv, (nd["mx"][ax] - o[ax]) * inv
+                    if inv < 0:
+                        t0, t1 = t1, t0
+                    lo = lo if lo > t0 else t0
+                    hi = hi if hi < t1 else t1
+                    if hi <= lo:
+                        ok = False
+                        break
+        if not ok:
+            assert nd["skip"] > i
+            i = int(nd["skip"])
+            continue
+        leaf = int(nd["leaf"])
+        if leaf:
+            typ, cnt, first = leaf >> 28, (leaf >> 24) & 15, leaf & 0xFFFFFF
+            assert typ == 1
+            for k in range(first, first + cnt):
+                c, r = spheres[k, :3].astype(float), float(spheres[k, 3])
+                oc = o - c
+                hb, cc = oc @ d, oc @ oc - r * r
+                det = hb * hb - a * cc
+                if det >= 0:
+                    sq = np.sqrt(det)
+                    root = (-hb - sq) / a
+                    if root < tmin or best < root:
+                        root = (-hb + sq) / a
+                        if root < tmin or best < root:
+                            continue
+                    best, hit = root, k
+        i += 1
+    return best, hit, visits
+
+
+def test_threaded_bvh_equals_oracle_world_hit(pkg, orc):
+    hs = pkg.HostScene("book1", 1)
+    nodes, spheres, meta = pkg.compile_dump(hs.desc)
+    info = pkg.compile_info(hs.desc)
+    assert info["n_box_nodes"] == len(nodes) == 511 or info["n_box_nodes"] <= len(nodes)
+    assert info["fits_lds"] == 1 and info["features"] == 0
+    # every skip edge goes forward; the last subtree's skip is the end sentinel
+    assert np.all(nodes["skip"] > np.arange(len(nodes))) and nodes["skip"].max() == len(nodes)
+    rng = np.random.default_rng(11)
+    n_hit = 0
+    for _ in range(150):
+        o = np.array([13, 2, 3]) + rng.normal(size=3) * 0.5
+        d = rng.normal(size=3) * [1, 0.3, 1] - o / 4
+        t, k, _ = traverse(nodes, spheres, o, d)
+        ref = orc.world_hit(hs.desc, o, d)
+        assert (ref is None) == (k < 0)
+        if ref is not None:
+            n_hit += 1
+            assert t == pytest.approx(ref["t"], rel=1e-5)
+    assert n_hit > 50
+
+
+def test_bvh_leaf_order_and_node_visits_match_the_oracle(pkg, orc):
+    """Same tree as the oracle's BVHNode::construct (bvh.rs:77-130 with the sub-range fix): same leaf
+    order, and the threaded walk performs exactly the oracle's Aabb::hit count on every ray."""
+    import ctypes as C
+    rng = np.random.default_rng(4)
+    b = pkg.SceneBuilder(bvh_seed=99)
+    m = b.lambertian((0.5, 0.5, 0.5))
+    ids = [b.sphere(rng.uniform(-8, 8, 3), rng.uniform(0.1, 1.0), m) for _ in range(137)]
+    root = b.bvh(ids)
+    desc = b.desc(root)
+    nodes, spheres, meta = pkg.compile_dump(desc)
+    out = (C.c_int32 * 256)()
+    n = orc.lib().orc_bvh_leaf_order(C.byref(desc), root, out, 256)
+    assert n == 137
+    oracle_centres = np.array([[desc.hittables[out[i]].p[k] for k in range(4)] for i in range(n)], dtype=np.float32)
+    assert np.array_equal(oracle_centres, spheres)          # compiler emits primitives in leaf order
+    cam = pkg.camera_new((0, 0, 30), (0, 0, 0), (0, 1, 0), 40, 1.0, 0.0, 10.0, 0, 0)
+    prm = pkg.make_params(8, 8, 1, max_depth=1)
+    _, st = orc.render(desc, cam, prm, precision=64, count=True)
+    # replay the same 64 camera rays through the python walk
+    visits = 0
+    _, f64, _ = orc.rng_stream(1, 0, 0, 1)
+    for y in range(8):
+        for x in range(8):
+            _, u, _ = orc.rng_stream(prm.seed, y * 8 + x, 0, 5)
+            j = 7 - y
+            s, t = (x + u[0]) / 7.0, (j + u[1]) / 7.0
+            o = np.array(cam.origin.tuple())
+            d = np.array(cam.lower_left_corner.tuple()) + np.array(cam.horizontal.tuple()) * s + np.array(cam.vertical.tuple()) * t - o
+            visits += traverse(nodes, spheres, o, d)[2]
+    assert visits == st["node_tests"]
+
+
+def test_compile_cornell(pkg):
+    hs = pkg.HostScene("cornell", 0)
+    info = pkg.compile_info(hs.desc)
+    assert info["n_rects"] == 12 and info["n_spheres"] == 1 and info["n_lights"] == 2 and info["n_xforms"] == 2
+    F_RECT, F_XFORM, F_LIGHTS = 2, 16, 64
+    assert info["features"] == F_RECT | F_XFORM | F_LIGHTS
+    nodes, _, _ = pkg.compile_dump(hs.desc)
+    types = [(int(n["leaf"]) >> 28, (int(n["leaf"]) >> 24) & 15) for n in nodes]
+    # list order of main.rs:353-431: 6 wall/light rects, ENTER, the box's 6 sides, EXIT, the glass sphere
+    assert types == [(3, 6), (6, 0), (3, 6), (7, 0), (1, 1)]
+
+
+def test_compile_rejects_malformed_graphs(pkg):
+    A = pkg._abi
+    b = pkg.SceneBuilder()
+    m = b.lambertian((1, 1, 1))
+    s = b.sphere((0, 0, 0), 1, m)
+    bad = b._hit(A.RT_HIT_SPHERE, 99, p=[0, 0, 0, 1])                 # material id out of range
+    with pytest.raises(pkg.RtError) as e:
+        pkg.compile_info(b.desc(b.hittable_list([s, bad])))
+    assert e.value.code == A.RT_ERR_INVALID
+    b = pkg.SceneBuilder()
+    with pytest.raises(pkg.RtError):
+        pkg.compile_info(b.desc(5))                                     # world id out of range
+    b = pkg.SceneBuilder()
+    m = b.lambertian((1, 1, 1))
+    tri = b.triangle((0, 0, 0), (1, 0, 0), (0, 1, 0), m)
+    med = b.constant_medium(tri, 0.1, (1, 1, 1))                        # boundary must be a sphere or a box
+    with pytest.raises(pkg.RtError) as e:
+        pkg.compile_info(b.desc(b.hittable_list([med])))
+    assert e.value.code == A.RT_ERR_UNSUPPORTED
+    b = pkg.SceneBuilder()
+    with pytest.raises(pkg.RtError):
+        pkg.compile_info(b.desc(b.bvh([])))                             # empty BVH
+
+
+def test_big_scene_compiles_fast(pkg):
+    import time
+    t = time.time()
+    hs = pkg.HostScene("big", 5, 200000, 64)
+    info = pkg.compile_info(hs.desc)
+    dt = time.time() - t
+    assert info["n_spheres"] == 200000 and info["n_tris"] == 2 * 64 * 32 and info["n_rects"] == 1
+    assert info["fits_lds"] == 0
+    assert dt < 60
