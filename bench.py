@@ -24,6 +24,24 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 NODE_BYTES, SPHERE_BYTES, RAY_BYTES, HIT_BYTES = 32, 20, 32, 8   # SURVEY.md §8(d) record sizes
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(math.ceil(int(q) / int(per)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(math.ceil(q / per))))
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get("RT_BENCH_CPU_THREADS", "64"))))
+
+
 def image_size(n_gpus, base_w=1200, base_h=800):
     """Same 3:2 view, N x the pixels (weak scaling)."""
     if n_gpus == 1:
@@ -160,10 +178,10 @@ def main():
     # ---- CPU baseline: the oracle (a port of the reference's CPU path), all host cores, bounded sample ----
     if n_gpus == 1 and args.cpu_seconds > 0:
         from oracle import binding as orc
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = host_cores()
         bw, bh = 1200, 800
         bcam = hs.camera(bw / bh)
-        probe = pkg.make_params(bw, bh, 1, max_depth=50, seed=1)
+        probe = pkg.make_params(bw, bh, 2, max_depth=50, seed=1)
         _, pst = orc.render(hs.desc, bcam, probe, precision=64, n_threads=cores)
         rate = pst["samples"] / max(pst["seconds"], 1e-6)
         spp_b = int(max(2, min(args.spp, args.cpu_seconds * rate / (bw * bh))))

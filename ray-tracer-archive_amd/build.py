@@ -8,7 +8,10 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librt_hip.so")
 SOURCES = ["csrc/kernels.hip", "csrc/rt_api.cpp", "csrc/scene_compile.cpp", "host/host_capi.cpp"]
 HEADERS = ["csrc/kernels.h", "csrc/device_types.h", "csrc/scene_compile.hpp", "host/rt_host.hpp", "../include/rt_hip.h", "../include/rt_host.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+# -ffp-contract=off: a float expression means the same IEEE operations wherever it is inlined, so a
+# sample's radiance does not depend on which kernel / call site generated its camera ray (and the
+# device evaluates the reference's expressions in the order written). Hot loops spell out fmaf/fma.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
 
 
 def needs_build():

@@ -151,14 +151,15 @@ DEVI V3 xform_normal_back(const rtd::Xform& x, V3 n) {
 // ground sphere, which turns into false self-hits beyond t_min = 0.001 at grazing angles.
 DEVI bool sphere_roots(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax, float& t) {
     const double ocx = (double)o.x - (double)c.x, ocy = (double)o.y - (double)c.y, ocz = (double)o.z - (double)c.z;
-    const double half_b = ocx * (double)d.x + ocy * (double)d.y + ocz * (double)d.z;
-    const double cc = ocx * ocx + ocy * ocy + ocz * ocz - (double)r * (double)r;
-    const double det = half_b * half_b - (double)a * cc;
+    const double half_b = fma(ocz, (double)d.z, fma(ocy, (double)d.y, ocx * (double)d.x));
+    const double cc = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -(double)r * (double)r)));
+    const double det = fma(half_b, half_b, -(double)a * cc);
     if (det < 0.0) return false;
     const double sq = sqrt(det);
-    float root = (float)((-half_b - sq) / (double)a);
+    const double inv_a = 1.0 / (double)a;
+    float root = (float)((-half_b - sq) * inv_a);
     if (root < tmin || tmax < root) {
-        root = (float)((-half_b + sq) / (double)a);
+        root = (float)((-half_b + sq) * inv_a);
         if (root < tmin || tmax < root) return false;
     }
     t = root;
