@@ -17,17 +17,19 @@ class RtError(RuntimeError):
 
 
 def lib_path():
-    return LIB_PATH
+    # RT_HIP_LIB selects a tuning build (scripts/ only); the default is the in-tree lib/librt_hip.so
+    return os.environ.get("RT_HIP_LIB", LIB_PATH)
 
 
 def lib():
     """Load librt_hip.so. Raises if it has not been built (python __graft_entry__.py / build.py)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RtError(A.RT_ERR_NO_DEVICE, f"{LIB_PATH} is missing: build it first (ray-tracer-archive_amd/build.py); "
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RtError(A.RT_ERR_NO_DEVICE, f"{path} is missing: build it first (ray-tracer-archive_amd/build.py); "
                           "the product path has no fallback")
-        _lib = A.declare(C.CDLL(LIB_PATH))
+        _lib = A.declare(C.CDLL(path))
         if _lib.rt_abi_version() != A.RT_ABI_VERSION:
             raise RtError(A.RT_ERR_INVALID, "librt_hip.so ABI version mismatch")
     return _lib

@@ -21,6 +21,21 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS)
 
 
+def build_variant(name, defines, verbose=False):
+    """Tuning builds: lib/variants/librt_hip_<name>.so with extra -D flags (scripts/ only)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    vdir = os.path.join(LIB_DIR, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    out = os.path.join(vdir, f"librt_hip_{name}.so")
+    cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + SOURCES + ["-lz"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    return out
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source of the package for gfx950. Raises on failure."""
     if not force and not needs_build():

@@ -34,11 +34,13 @@ struct SceneDev {
 
 // Path pool: structure of arrays, one 16-byte lane-contiguous record per array and slot.
 //   ray_o = (origin.xyz, time)         ray_d = (direction.xyz, -)         hit = (t, primitive id)
-//   s0 = (T.rgb, L.r)  s1 = (L.gb, acc.rg)  s2 = (acc.b, work, sample_in_block<<8|depth, rng.lo)
-//   s3 = (rng.hi, base.lo, base.hi, -)
+//   s0 = (T.rgb, L.r)  s1 = (L.gb, acc.rg)  s2 = (acc.b, work item, sample<<8|depth, x|y<<16)
+//   s3 = rng counter (u64)
+// 104 bytes per path: T = throughput, L = radiance of the current sample, acc = sum over the finished
+// samples of the current work item.
 struct PoolDev {
     rtd::Float4* ray_o; rtd::Float4* ray_d; uint2* hit;
-    rtd::Float4* s0; rtd::Float4* s1; rtd::Float4* s2; rtd::Float4* s3;
+    rtd::Float4* s0; rtd::Float4* s1; rtd::Float4* s2; uint2* s3;
 };
 
 struct RenderDev {
@@ -51,9 +53,11 @@ struct RenderDev {
     int32_t bg_mode; float bg[3];
     // framebuffer tiling / work decomposition
     uint32_t tile_size, tiles_x, tiles_y, shard_index, shard_count;
-    uint32_t block_len;     // samples per work item
-    uint32_t n_blocks;      // work items per pixel = ceil(spp / block_len)
-    uint32_t total_items;   // n_local_tiles * n_blocks * tile_size^2
+    uint32_t block_shift;   // a work item covers 1 << block_shift consecutive samples of one pixel
+    uint32_t n_blocks;      // work items per pixel = ceil(spp >> block_shift)
+    uint32_t total_items;   // in-image pixels of this shard * n_blocks
+    uint32_t n_local_tiles;
+    const uint32_t* tile_prefix;  // [n_local_tiles + 1]: in-image pixels in local tiles before lt
     rtd::Float4* blocksum;  // [total_items]: RGB sum of one work item's samples
 };
 
@@ -68,7 +72,7 @@ hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev
                          uint32_t* head, unsigned long long* counters, bool count, hipStream_t stream);
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
                         const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, unsigned long long* counters, bool count, hipStream_t stream);
-hipError_t launch_resolve(const RenderDev& rd, float* out, uint32_t n_local_tiles, hipStream_t stream);
+hipError_t launch_resolve(const RenderDev& rd, float* out, uint32_t n_valid_pixels, hipStream_t stream);
 hipError_t launch_write_color(const float* rgb_sum, uint32_t n_pixels, uint32_t spp, uint8_t* rgb8, hipStream_t stream);
 
 }  // namespace rtk

@@ -146,24 +146,44 @@ DEVI V3 xform_normal_back(const rtd::Xform& x, V3 n) {
 // ------------------------------------------------------------------------------------------------
 // primitive tests (closest-hit interval [tmin, tmax], both ends inclusive like the reference)
 // ------------------------------------------------------------------------------------------------
-// Sphere::hit (sphere.rs:41-65). The quadratic's coefficients are formed in f64: the reference is
-// f64 throughout, and in f32 `oc.length_squared() - r*r` loses ~0.1 absolute for the r = 1000
-// ground sphere, which turns into false self-hits beyond t_min = 0.001 at grazing angles.
+// Sphere::hit (sphere.rs:41-65): half-b quadratic, near root first, then the far root, inclusive bounds.
+// Numerics: the reference is f64. In f32, `oc.length_squared() - r*r` loses ~0.1 absolute for the
+// r = 1000 ground sphere, which becomes false self-hits beyond t_min = 0.001 at grazing angles. So:
+//   1. a conservative f32 test throws out certain misses (most tests);
+//   2. survivors form oc, half_b, c and the discriminant with f64 FMAs (no f64 sqrt / divide);
+//   3. the two roots come from the cancellation-free pair q/a and c/q in f32.
+DEVI bool sphere_certain_miss(V3 o, V3 d, float a, V3 c, float r) {
+    const V3 oc = o - c;
+    const float hb = dot(oc, d), l2 = dot(oc, oc), r2 = r * r;
+    const float cc = l2 - r2;
+    const float det = fmaf(hb, hb, -a * cc);
+    const float scale = l2 + r2;
+    if (det < -2e-6f * fmaf(a, scale, hb * hb)) return true;                          // no real root, with margin
+    return hb > 0.f && hb * hb > 1e-10f * (l2 * a) && cc > 4e-6f * scale;                // outside and pointing away: both roots < 0
+}
 DEVI bool sphere_roots(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax, float& t) {
     const double ocx = (double)o.x - (double)c.x, ocy = (double)o.y - (double)c.y, ocz = (double)o.z - (double)c.z;
     const double half_b = fma(ocz, (double)d.z, fma(ocy, (double)d.y, ocx * (double)d.x));
     const double cc = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -(double)r * (double)r)));
     const double det = fma(half_b, half_b, -(double)a * cc);
     if (det < 0.0) return false;
-    const double sq = sqrt(det);
-    const double inv_a = 1.0 / (double)a;
-    float root = (float)((-half_b - sq) * inv_a);
+    const float hbf = (float)half_b, ccf = (float)cc;
+    const float sq = sqrtf((float)det);
+    const float q = hbf > 0.f ? -(hbf + sq) : (sq - hbf);   // -half_b -/+ sqrt(det) without cancellation
+    if (q == 0.f) return false;                              // double root at t = 0
+    const float tq = q / a, tc = ccf / q;
+    const float t_near = hbf > 0.f ? tq : tc, t_far = hbf > 0.f ? tc : tq;   // (-hb - sq)/a and (-hb + sq)/a
+    float root = t_near;
     if (root < tmin || tmax < root) {
-        root = (float)((-half_b + sq) * inv_a);
+        root = t_far;
         if (root < tmin || tmax < root) return false;
     }
     t = root;
     return true;
+}
+DEVI bool sphere_hit(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax, float& t) {
+    if (sphere_certain_miss(o, d, a, c, r)) return false;
+    return sphere_roots(o, d, a, c, r, tmin, tmax, t);
 }
 DEVI V3 moving_center(Float4 m0, Float4 m1, Float4 m2, float time) {           // moving_sphere.rs:36-39
     const float f = (time - m1.w) / (m2.x - m1.w);
@@ -241,9 +261,24 @@ DEVI bool medium_hit(const SceneDev& sc, const rtd::Medium& m, V3 ow, V3 dw, flo
 // ------------------------------------------------------------------------------------------------
 // k_extend — world.hit for the whole pool
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kChunk = 256;   // rays a wave takes from the queue head per atomic
-constexpr int kSteps = 8;          // node visits between refill checks
+#ifndef RT_CHUNK
+#define RT_CHUNK 256        // rays a wave takes from the queue head per atomic
+#endif
+#ifndef RT_STEPS
+#define RT_STEPS 4          // node visits between two looks at the leaf batch / the refill
+#endif
+#ifndef RT_LEAF_BATCH
+#define RT_LEAF_BATCH 16    // lanes with a pending leaf that trigger a primitive-test pass
+#endif
+constexpr uint32_t kChunk = RT_CHUNK;
+constexpr int kSteps = RT_STEPS;
+constexpr int kLeafBatch = RT_LEAF_BATCH;
 
+// Lane-level state machine: a lane with a ray either walks nodes (pend == 0) or waits with a leaf whose
+// primitives are still to be tested (pend = the node's leaf word). Node visits and primitive tests run
+// in separate passes so that each pass keeps many lanes busy: a primitive test (f64 refinement) costs
+// several node visits, and in lock step with node visits it would run with one or two active lanes.
+// Per lane the ORDER of events is unchanged: the leaf is tested before the lane visits its next node.
 template <bool LDS, uint32_t FEAT, bool COUNT>
 __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
                                                  uint32_t* __restrict__ head, unsigned long long* __restrict__ counters,
@@ -265,7 +300,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
     bool exhausted = false;
 
     bool have = false;
-    uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE;
+    uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE, pend = 0;
     float tmax = kInf, tm = 0.f, a = 1.f;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0), oi = v3(0, 0, 0);
     V3 ow = o, dw = d;                 // world ray while inside an instance transform
@@ -273,6 +308,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
     unsigned long long c_nodes = 0, c_prims[RT_N_PRIM_TYPES_K] = {0, 0, 0, 0, 0, 0};
 
     for (;;) {
+        // ---- refill: idle lanes take the next rays of this wave's chunk (ballot + prefix rank) ----
         const uint64_t idle = __ballot(!have);
         if (idle != 0ull && !exhausted) {
             uint32_t avail = w_end - w_next;
@@ -294,11 +330,12 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
                     a = len2(d);
                     if (FEAT & F_XFORM) { ow = o; dw = d; }
                     if (FEAT & F_MEDIUM) {
-                        const Float4 s2 = pool.s2[slot], s3 = pool.s3[slot];
-                        seg = __float_as_uint(s2.z) & 0xFFu;
-                        mkey = (uint64_t)__float_as_uint(s3.y) | ((uint64_t)__float_as_uint(s3.z) << 32);
+                        const Float4 s2 = pool.s2[slot];
+                        const uint32_t sd = __float_as_uint(s2.z), xy = __float_as_uint(s2.w);
+                        seg = sd & 0xFFu;
+                        mkey = path_base(rd.seed, (uint64_t)(xy >> 16) * rd.width + (xy & 0xFFFFu), sd >> 8);
                     }
-                    tmax = kInf; node = 0; hit_prim = rtd::HIT_NONE; have = true;
+                    tmax = kInf; node = 0; hit_prim = rtd::HIT_NONE; pend = 0; have = true;
                 }
                 const uint32_t n_idle = (uint32_t)__popcll(idle);
                 w_next += min(n_idle, avail);
@@ -306,9 +343,10 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
         }
         if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
 
+        // ---- node pass ----
 #pragma unroll 1
         for (int step = 0; step < kSteps; ++step) {
-            if (have) {
+            if (have && pend == 0u) {
                 if (node >= n_nodes) {
                     pool.hit[slot] = make_uint2(__float_as_uint(tmax), hit_prim);
                     have = false;
@@ -325,56 +363,65 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
                     const bool boxhit = tnear <= tfar * 1.0000004f;   // padded by 3 ulp: never cull a true hit
                     if (COUNT) { if (n0.x > -kInf) c_nodes++; }
                     if (boxhit) {
-                        if (leaf != 0u) {
-                            const uint32_t type = leaf >> 28, cnt = (leaf >> 24) & 15u, first = leaf & rtd::LEAF_MAX_FIRST;
-                            if (type == rtd::LT_SPHERE) {
-                                for (uint32_t k = 0; k < cnt; ++k) {
-                                    const float4 s = spheres[first + k];
-                                    float t;
-                                    if (COUNT) c_prims[0]++;
-                                    if (sphere_roots(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t)) { tmax = t; hit_prim = (rtd::LT_SPHERE << 28) | (first + k); }
-                                }
-                            } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
-                                for (uint32_t k = 0; k < cnt; ++k) {
-                                    const Float4 r0 = sc.rects[2 * (first + k)], r1 = sc.rects[2 * (first + k) + 1];
-                                    float t, ha, hb;
-                                    if (COUNT) c_prims[2]++;
-                                    if (rect_hit(o, d, r0, r1, kTMin, tmax, t, ha, hb)) { tmax = t; hit_prim = (rtd::LT_RECT << 28) | (first + k); }
-                                }
-                            } else if ((FEAT & F_MOVING) && type == rtd::LT_MOVING) {
-                                for (uint32_t k = 0; k < cnt; ++k) {
-                                    const Float4 m0 = sc.moving[3 * (first + k)], m1 = sc.moving[3 * (first + k) + 1], m2 = sc.moving[3 * (first + k) + 2];
-                                    float t;
-                                    if (COUNT) c_prims[1]++;
-                                    if (sphere_roots(o, d, a, moving_center(m0, m1, m2, tm), m0.w, kTMin, tmax, t)) { tmax = t; hit_prim = (rtd::LT_MOVING << 28) | (first + k); }
-                                }
-                            } else if ((FEAT & F_TRI) && type == rtd::LT_TRI) {
-                                for (uint32_t k = 0; k < cnt; ++k) {
-                                    const Float4 t0 = sc.tris[3 * (first + k)], t1 = sc.tris[3 * (first + k) + 1], t2 = sc.tris[3 * (first + k) + 2];
-                                    float t, bu, bv;
-                                    if (COUNT) c_prims[3]++;
-                                    if (tri_hit(o, d, f4xyz(t0), f4xyz(t1), f4xyz(t2), kTMin, tmax, t, bu, bv)) { tmax = t; hit_prim = (rtd::LT_TRI << 28) | (first + k); }
-                                }
-                            } else if ((FEAT & F_MEDIUM) && type == rtd::LT_MEDIUM) {
-                                const rtd::Medium m = sc.media[first];
-                                const float xi = u01(medium_bits(mkey, seg, m.medium_id));
-                                float t;
-                                if (COUNT) c_prims[4]++;
-                                const V3 mo = (FEAT & F_XFORM) ? ow : o, md = (FEAT & F_XFORM) ? dw : d;
-                                if (medium_hit(sc, m, mo, md, kTMin, tmax, xi, t)) { tmax = t; hit_prim = (rtd::LT_MEDIUM << 28) | first; }
-                            } else if ((FEAT & F_XFORM) && (type == rtd::LT_ENTER || type == rtd::LT_EXIT)) {
-                                if (first == 0u) { o = ow; d = dw; }
-                                else xform_ray(sc.xforms[first], ow, dw, o, d);
-                                inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                                oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
-                                if (COUNT) { if (type == rtd::LT_ENTER) c_prims[5]++; }
-                            }
-                        }
+                        const uint32_t type = leaf >> 28;
+                        if ((FEAT & F_XFORM) && (type == rtd::LT_ENTER || type == rtd::LT_EXIT)) {
+                            const uint32_t xf = leaf & rtd::LEAF_MAX_FIRST;
+                            if (xf == 0u) { o = ow; d = dw; }
+                            else xform_ray(sc.xforms[xf], ow, dw, o, d);
+                            inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                            oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+                            if (COUNT) { if (type == rtd::LT_ENTER) c_prims[5]++; }
+                        } else pend = leaf;            // 0 for an inner node
                         node = node + 1u;
                     } else {
                         node = skip;
                     }
                 }
+            }
+        }
+
+        // ---- primitive pass: when enough lanes hold a leaf, or nobody can walk any further ----
+        const uint64_t pm = __ballot(pend != 0u);
+        if (pm == 0ull) continue;
+        if ((int)__popcll(pm) < kLeafBatch && __ballot(have && pend == 0u) != 0ull) continue;
+        if (pend != 0u) {
+            const uint32_t type = pend >> 28, cnt = (pend >> 24) & 15u, first = pend & rtd::LEAF_MAX_FIRST;
+            pend = 0u;
+            if (type == rtd::LT_SPHERE) {
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4 s = spheres[first + k];
+                    float t;
+                    if (COUNT) c_prims[0]++;
+                    if (sphere_hit(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t)) { tmax = t; hit_prim = (rtd::LT_SPHERE << 28) | (first + k); }
+                }
+            } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const Float4 r0 = sc.rects[2 * (first + k)], r1 = sc.rects[2 * (first + k) + 1];
+                    float t, ha, hb;
+                    if (COUNT) c_prims[2]++;
+                    if (rect_hit(o, d, r0, r1, kTMin, tmax, t, ha, hb)) { tmax = t; hit_prim = (rtd::LT_RECT << 28) | (first + k); }
+                }
+            } else if ((FEAT & F_MOVING) && type == rtd::LT_MOVING) {
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const Float4 m0 = sc.moving[3 * (first + k)], m1 = sc.moving[3 * (first + k) + 1], m2 = sc.moving[3 * (first + k) + 2];
+                    float t;
+                    if (COUNT) c_prims[1]++;
+                    if (sphere_hit(o, d, a, moving_center(m0, m1, m2, tm), m0.w, kTMin, tmax, t)) { tmax = t; hit_prim = (rtd::LT_MOVING << 28) | (first + k); }
+                }
+            } else if ((FEAT & F_TRI) && type == rtd::LT_TRI) {
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const Float4 t0 = sc.tris[3 * (first + k)], t1 = sc.tris[3 * (first + k) + 1], t2 = sc.tris[3 * (first + k) + 2];
+                    float t, bu, bv;
+                    if (COUNT) c_prims[3]++;
+                    if (tri_hit(o, d, f4xyz(t0), f4xyz(t1), f4xyz(t2), kTMin, tmax, t, bu, bv)) { tmax = t; hit_prim = (rtd::LT_TRI << 28) | (first + k); }
+                }
+            } else if ((FEAT & F_MEDIUM) && type == rtd::LT_MEDIUM) {
+                const rtd::Medium m = sc.media[first];
+                const float xi = u01(medium_bits(mkey, seg, m.medium_id));
+                float t;
+                if (COUNT) c_prims[4]++;
+                const V3 mo = (FEAT & F_XFORM) ? ow : o, md = (FEAT & F_XFORM) ? dw : d;
+                if (medium_hit(sc, m, mo, md, kTMin, tmax, xi, t)) { tmax = t; hit_prim = (rtd::LT_MEDIUM << 28) | first; }
             }
         }
     }
@@ -394,29 +441,54 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
 // ------------------------------------------------------------------------------------------------
 // work items, camera rays
 // ------------------------------------------------------------------------------------------------
-struct WorkItem { uint32_t x, y, blk; bool valid; };
-DEVI WorkItem decode_work(const RenderDev& rd, uint32_t w) {
-    const uint32_t ts2 = rd.tile_size * rd.tile_size;
-    const uint32_t pix = w % ts2;
-    const uint32_t q = w / ts2;
-    const uint32_t blk = q % rd.n_blocks;
-    const uint32_t lt = q / rd.n_blocks;
+// A work item = (pixel, block of `block_len` consecutive samples). Items are numbered tile by tile over
+// this shard's tiles; tile_prefix[lt] = number of in-image pixels in local tiles < lt, so every item
+// maps to a pixel inside the image (edge tiles are clipped, not padded).
+struct WorkItem { uint32_t x, y, blk; };
+struct TileGeom { uint32_t x0, y0, w, h; };
+DEVI TileGeom tile_geom(const RenderDev& rd, uint32_t lt) {
     const uint32_t tile = rd.shard_index + lt * rd.shard_count;
     const uint32_t tx = tile % rd.tiles_x, ty = tile / rd.tiles_x;
-    // 8x8 pixel squares inside the tile: one wave's 64 consecutive items cover a square
-    const uint32_t sq = pix >> 6, in = pix & 63u, sq_per_row = rd.tile_size >> 3;
-    const uint32_t px = (sq % sq_per_row) * 8u + (in & 7u), py = (sq / sq_per_row) * 8u + (in >> 3);
+    TileGeom g;
+    g.x0 = tx * rd.tile_size; g.y0 = ty * rd.tile_size;
+    g.w = min(rd.tile_size, rd.width - g.x0); g.h = min(rd.tile_size, rd.height - g.y0);
+    return g;
+}
+DEVI void tile_pixel(const RenderDev& rd, const TileGeom& g, uint32_t p, uint32_t& px, uint32_t& py) {
+    if (g.w == rd.tile_size && g.h == rd.tile_size) {
+        // full tile: 8x8 pixel squares, so a wave's 64 consecutive items cover one square
+        const uint32_t sq = p >> 6, in = p & 63u, sq_per_row = rd.tile_size >> 3;
+        px = (sq % sq_per_row) * 8u + (in & 7u); py = (sq / sq_per_row) * 8u + (in >> 3);
+    } else { px = p % g.w; py = p / g.w; }
+}
+DEVI uint32_t find_tile(const RenderDev& rd, uint64_t key, uint32_t scale, uint32_t lo) {
+    // largest lt with tile_prefix[lt] * scale <= key
+    uint32_t hi = rd.n_local_tiles - 1u;
+    lo = min(lo, hi);
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if ((uint64_t)rd.tile_prefix[mid] * scale <= key) lo = mid; else hi = mid - 1u;
+    }
+    return lo;
+}
+DEVI WorkItem decode_work(const RenderDev& rd, uint32_t w) {
+    const uint32_t ts2 = rd.tile_size * rd.tile_size;
+    const uint32_t lt = find_tile(rd, w, rd.n_blocks, w / (ts2 * rd.n_blocks));
+    const TileGeom g = tile_geom(rd, lt);
+    const uint32_t valid = g.w * g.h;
+    const uint32_t r = w - rd.tile_prefix[lt] * rd.n_blocks;
     WorkItem it;
-    it.x = tx * rd.tile_size + px; it.y = ty * rd.tile_size + py; it.blk = blk;
-    it.valid = it.x < rd.width && it.y < rd.height;
+    it.blk = r / valid;
+    uint32_t px, py;
+    tile_pixel(rd, g, r - it.blk * valid, px, py);
+    it.x = g.x0 + px; it.y = g.y0 + py;
     return it;
 }
 
 // One new sample: jitter (main.rs:752-753) then Camera::get_ray (camera.rs:60-70).
-DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t sample, Rng& g, uint64_t& base, V3& o, V3& d, float& tm) {
+DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t sample, Rng& g, V3& o, V3& d, float& tm) {
     const uint64_t pixel_index = (uint64_t)y * rd.width + x;
-    base = path_base(rd.seed, pixel_index, sample);
-    g.s = base;
+    g.s = path_base(rd.seed, pixel_index, sample);
     const float ju = g.rnd(), jv = g.rnd();
     const uint32_t j = rd.height - 1u - y;                       // main.rs:733
     const float u = ((float)x + ju) / (float)(rd.width - 1u);    // main.rs:752
@@ -438,55 +510,57 @@ DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t s
 
 struct PathState {
     V3 T, L, acc;
-    uint32_t work, sdepth;   // sdepth = sample_in_block << 8 | depth
-    uint64_t rng, base;
+    uint32_t work, sdepth, xy;   // sdepth = sample index << 8 | depth;  xy = x | y << 16
+    uint64_t rng;
 };
 DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const PathState& s) {
     p.ray_o[i] = Float4{o.x, o.y, o.z, tm};
     p.ray_d[i] = Float4{d.x, d.y, d.z, 0.f};
     p.s0[i] = Float4{s.T.x, s.T.y, s.T.z, s.L.x};
     p.s1[i] = Float4{s.L.y, s.L.z, s.acc.x, s.acc.y};
-    p.s2[i] = Float4{s.acc.z, __uint_as_float(s.work), __uint_as_float(s.sdepth), __uint_as_float((uint32_t)s.rng)};
-    p.s3[i] = Float4{__uint_as_float((uint32_t)(s.rng >> 32)), __uint_as_float((uint32_t)s.base), __uint_as_float((uint32_t)(s.base >> 32)), 0.f};
+    p.s2[i] = Float4{s.acc.z, __uint_as_float(s.work), __uint_as_float(s.sdepth), __uint_as_float(s.xy)};
+    p.s3[i] = make_uint2((uint32_t)s.rng, (uint32_t)(s.rng >> 32));
 }
 
-// Take work items until one maps to a pixel inside the image (edge tiles), or the queue is empty.
-// Wave-aggregated: one atomicAdd per wave per round. Returns false if no work is left.
-DEVI bool take_work(const RenderDev& rd, uint32_t* next_work, bool want, uint32_t& work, WorkItem& it) {
-    bool got = false;
-    for (;;) {
-        const uint64_t m = __ballot(want && !got);
-        if (m == 0ull) break;
-        uint32_t base = 0;
-        const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-        if ((threadIdx.x & 63u) == leader) base = atomicAdd(next_work, (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, (int)leader);
-        if (want && !got) {
-            const uint32_t w = base + lane_rank(m);
-            if (w >= rd.total_items) want = false;
-            else { it = decode_work(rd, w); if (it.valid) { work = w; got = true; } }
-        }
-    }
-    return got;
+// Workgroup-aggregated allocation: every thread of the block calls it; threads with `flag` get
+// consecutive indices from *counter (ONE returning atomic per workgroup: same-address atomics
+// serialise at the L2, so per-wave atomics would bound the kernel). wave64 ballot + prefix inside a
+// wave, a tiny LDS scan across waves.
+constexpr uint32_t kShadeThreads = 512;
+DEVI uint32_t block_alloc(bool flag, uint32_t* counter, uint32_t* s_scan) {
+    const uint32_t wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint64_t m = __ballot(flag);
+    if ((threadIdx.x & 63u) == 0u) s_scan[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t prefix = 0, total = 0;
+    for (uint32_t w = 0; w < nw; ++w) { const uint32_t c = s_scan[w]; prefix += (w < wave) ? c : 0u; total += c; }
+    if (threadIdx.x == 0u && total != 0u) s_scan[nw] = atomicAdd(counter, total);
+    __syncthreads();
+    const uint32_t base = s_scan[nw];
+    __syncthreads();
+    return flag ? base + prefix + lane_rank(m) : 0xFFFFFFFFu;
 }
 
-__global__ void __launch_bounds__(256) k_generate(PoolDev pool, RenderDev rd, uint32_t n_init, uint32_t* __restrict__ next_work, uint32_t* __restrict__ out_count) {
+// A fresh path for work item `work` (first sample of its block).
+DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, V3& o, V3& d, float& tm) {
+    const WorkItem it = decode_work(rd, work);
+    Rng g;
+    const uint32_t sample = it.blk << rd.block_shift;
+    new_camera_ray(rd, it.x, it.y, sample, g, o, d, tm);
+    s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); s.acc = v3(0, 0, 0);
+    s.work = work; s.sdepth = sample << 8; s.xy = it.x | (it.y << 16); s.rng = g.s;
+}
+
+__global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, RenderDev rd, uint32_t n_init, uint32_t* __restrict__ next_work, uint32_t* __restrict__ out_count) {
+    __shared__ uint32_t s_scan[kShadeThreads / 64 + 1];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool want = i < n_init;
-    uint32_t work = 0; WorkItem it{};
-    const bool got = take_work(rd, next_work, want, work, it);
-    // dense write of the slots that got work
-    const uint64_t m = __ballot(got);
-    if (m == 0ull) return;
-    uint32_t base = 0;
-    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-    if ((threadIdx.x & 63u) == leader) base = atomicAdd(out_count, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, (int)leader);
+    const uint32_t work = block_alloc(i < n_init, next_work, s_scan);
+    const bool got = work < rd.total_items;
+    const uint32_t dst = block_alloc(got, out_count, s_scan);
     if (got) {
-        PathState s; Rng g; V3 o, d; float tm;
-        new_camera_ray(rd, it.x, it.y, it.blk * rd.block_len, g, s.base, o, d, tm);
-        s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); s.acc = v3(0, 0, 0); s.work = work; s.sdepth = 0; s.rng = g.s;
-        store_path(pool, base + lane_rank(m), o, d, tm, s);
+        PathState s; V3 o, d; float tm;
+        start_item(rd, work, s, o, d, tm);
+        store_path(pool, dst, o, d, tm, s);
     }
 }
 
@@ -596,9 +670,10 @@ DEVI void sphere_uv(V3 p, float& u, float& v) {                                /
 }
 
 template <uint32_t FEAT, bool COUNT>
-__global__ void __launch_bounds__(256) k_shade(SceneDev sc, PoolDev in, PoolDev out, RenderDev rd, const uint32_t* __restrict__ count_in_ptr,
+__global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in, PoolDev out, RenderDev rd, const uint32_t* __restrict__ count_in_ptr,
                                                 uint32_t* __restrict__ count_out, uint32_t* __restrict__ next_work,
                                                 unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t s_scan[kShadeThreads / 64 + 1];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t count_in = *count_in_ptr;
     bool alive = i < count_in;
@@ -606,15 +681,14 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, PoolDev in, PoolDev 
     unsigned long long c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
     bool want_work = false;
     if (alive) {
-        const Float4 ro = in.ray_o[i], rdv = in.ray_d[i], s0 = in.s0[i], s1 = in.s1[i], s2 = in.s2[i], s3 = in.s3[i];
-        const uint2 hit = in.hit[i];
+        const Float4 ro = in.ray_o[i], rdv = in.ray_d[i], s0 = in.s0[i], s1 = in.s1[i], s2 = in.s2[i];
+        const uint2 s3 = in.s3[i], hit = in.hit[i];
         o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
         s.T = v3(s0.x, s0.y, s0.z); s.L = v3(s0.w, s1.x, s1.y); s.acc = v3(s1.z, s1.w, s2.x);
-        s.work = __float_as_uint(s2.y); s.sdepth = __float_as_uint(s2.z);
-        s.rng = (uint64_t)__float_as_uint(s2.w) | ((uint64_t)__float_as_uint(s3.x) << 32);
-        s.base = (uint64_t)__float_as_uint(s3.y) | ((uint64_t)__float_as_uint(s3.z) << 32);
+        s.work = __float_as_uint(s2.y); s.sdepth = __float_as_uint(s2.z); s.xy = __float_as_uint(s2.w);
+        s.rng = (uint64_t)s3.x | ((uint64_t)s3.y << 32);
         Rng g; g.s = s.rng;
-        uint32_t depth = s.sdepth & 0xFFu, sib = s.sdepth >> 8;
+        uint32_t depth = s.sdepth & 0xFFu, sample = s.sdepth >> 8;
         bool finished = false;
 
         if (hit.y == rtd::HIT_NONE) {
@@ -759,12 +833,9 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, PoolDev in, PoolDev 
             const bool fin_ok = (fabsf(L.x) < kInf) && (fabsf(L.y) < kInf) && (fabsf(L.z) < kInf);
             if (!fin_ok && rd.nan_policy == RT_NAN_PER_SAMPLE_K) L = v3(0.f, 0.f, 0.f);
             s.acc = s.acc + L;
-            sib++;
-            const WorkItem it = decode_work(rd, s.work);
-            const uint32_t first_sample = it.blk * rd.block_len;
-            const uint32_t this_len = min(rd.block_len, rd.spp - first_sample);
-            if (sib < this_len) {
-                new_camera_ray(rd, it.x, it.y, first_sample + sib, g, s.base, o, d, tm);
+            sample++;
+            if ((sample & ((1u << rd.block_shift) - 1u)) != 0u && sample < rd.spp) {
+                new_camera_ray(rd, s.xy & 0xFFFFu, s.xy >> 16, sample, g, o, d, tm);   // next sample of the same block
                 s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); depth = 0;
             } else {
                 rd.blocksum[s.work] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
@@ -772,30 +843,22 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, PoolDev in, PoolDev 
             }
         }
         s.rng = g.s;
-        s.sdepth = (sib << 8) | depth;
+        s.sdepth = (sample << 8) | depth;
     }
 
-    // ---- regeneration: a slot whose block is complete draws a new work item ----
-    if (__ballot(want_work) != 0ull) {
-        uint32_t work = 0; WorkItem it{};
-        const bool got = take_work(rd, next_work, want_work, work, it);
+    // ---- regeneration: a slot whose block is complete draws a new work item (one atomic per workgroup) ----
+    {
+        const uint32_t work = block_alloc(want_work, next_work, s_scan);
         if (want_work) {
-            if (got) {
-                Rng g;
-                new_camera_ray(rd, it.x, it.y, it.blk * rd.block_len, g, s.base, o, d, tm);
-                s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); s.acc = v3(0, 0, 0); s.work = work; s.sdepth = 0; s.rng = g.s;
-            } else alive = false;
+            if (work < rd.total_items) start_item(rd, work, s, o, d, tm);
+            else alive = false;
         }
     }
 
-    // ---- compaction: survivors go to the other pool densely (wave64 ballot + prefix) ----
-    const uint64_t m = __ballot(alive);
-    if (m != 0ull) {
-        uint32_t base = 0;
-        const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-        if ((threadIdx.x & 63u) == leader) base = atomicAdd(count_out, (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, (int)leader);
-        if (alive) store_path(out, base + lane_rank(m), o, d, tm, s);
+    // ---- compaction: survivors go to the other pool densely (wave64 ballot + prefix, LDS scan across waves) ----
+    {
+        const uint32_t dst = block_alloc(alive, count_out, s_scan);
+        if (alive) store_path(out, dst, o, d, tm, s);
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { c_samples += __shfl_down(c_samples, off); c_light_rect += __shfl_down(c_light_rect, off); c_light_sphere += __shfl_down(c_light_sphere, off); }
@@ -810,27 +873,24 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, PoolDev in, PoolDev 
 // ------------------------------------------------------------------------------------------------
 // k_resolve — per-pixel sum of block sums, in block order
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_resolve(RenderDev rd, float* __restrict__ out, uint32_t n_local_tiles) {
+__global__ void __launch_bounds__(256) k_resolve(RenderDev rd, float* __restrict__ out) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per in-image pixel of this shard
+    if (gid >= rd.tile_prefix[rd.n_local_tiles]) return;
     const uint32_t ts2 = rd.tile_size * rd.tile_size;
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (uint64_t)n_local_tiles * ts2) return;
-    const uint32_t lt = (uint32_t)(gid / ts2), pix = (uint32_t)(gid % ts2);
-    float r = 0.f, g = 0.f, b = 0.f;
+    const uint32_t lt = find_tile(rd, gid, 1u, gid / ts2);
+    const TileGeom g = tile_geom(rd, lt);
+    const uint32_t valid = g.w * g.h, p = gid - rd.tile_prefix[lt];
+    const uint64_t base = (uint64_t)rd.tile_prefix[lt] * rd.n_blocks + p;
+    float r = 0.f, gg = 0.f, b = 0.f;
     for (uint32_t blk = 0; blk < rd.n_blocks; ++blk) {
-        const Float4 v = rd.blocksum[((uint64_t)lt * rd.n_blocks + blk) * ts2 + pix];
-        r += v.x; g += v.y; b += v.z;
+        const Float4 v = rd.blocksum[base + (uint64_t)blk * valid];
+        r += v.x; gg += v.y; b += v.z;
     }
-    const WorkItem it = decode_work(rd, (uint32_t)((uint64_t)lt * rd.n_blocks * ts2 + pix));
-    if (rd.shard_count <= 1u) {
-        if (it.valid) { float* q = out + ((uint64_t)it.y * rd.width + it.x) * 3u; q[0] = r; q[1] = g; q[2] = b; }
-    } else {
-        // tile-compact layout, row-major inside the tile; pixels outside the image are 0
-        const uint32_t tile = rd.shard_index + lt * rd.shard_count;
-        const uint32_t tx = tile % rd.tiles_x, ty = tile / rd.tiles_x;
-        const uint32_t px = it.x - tx * rd.tile_size, py = it.y - ty * rd.tile_size;
-        float* q = out + ((uint64_t)lt * ts2 + (uint64_t)py * rd.tile_size + px) * 3u;
-        q[0] = it.valid ? r : 0.f; q[1] = it.valid ? g : 0.f; q[2] = it.valid ? b : 0.f;
-    }
+    uint32_t px, py;
+    tile_pixel(rd, g, p, px, py);
+    float* q = rd.shard_count <= 1u ? out + ((uint64_t)(g.y0 + py) * rd.width + (g.x0 + px)) * 3u
+                                    : out + ((uint64_t)lt * ts2 + (uint64_t)py * rd.tile_size + px) * 3u;   // tile-compact layout
+    q[0] = r; q[1] = gg; q[2] = b;
 }
 
 // write_color (main.rs:141-169) on the device
@@ -871,31 +931,30 @@ hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev
 
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
                         const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, unsigned long long* counters, bool count, hipStream_t stream) {
-    const uint32_t blocks = (max_count + 255u) / 256u;
+    const uint32_t blocks = (max_count + kShadeThreads - 1u) / kShadeThreads;
     if (blocks == 0u) return hipSuccess;
     const bool simple = (cfg.features == 0u);
     if (simple) {
-        if (count) hipLaunchKernelGGL((k_shade<0u, true>), dim3(blocks), dim3(256), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
-        else hipLaunchKernelGGL((k_shade<0u, false>), dim3(blocks), dim3(256), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
+        if (count) hipLaunchKernelGGL((k_shade<0u, true>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
+        else hipLaunchKernelGGL((k_shade<0u, false>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
     } else {
-        if (count) hipLaunchKernelGGL((k_shade<F_ALL, true>), dim3(blocks), dim3(256), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
-        else hipLaunchKernelGGL((k_shade<F_ALL, false>), dim3(blocks), dim3(256), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
+        if (count) hipLaunchKernelGGL((k_shade<F_ALL, true>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
+        else hipLaunchKernelGGL((k_shade<F_ALL, false>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_init, uint32_t* next_work, uint32_t* out_count, hipStream_t stream) {
-    const uint32_t blocks = (n_init + 255u) / 256u;
+    const uint32_t blocks = (n_init + kShadeThreads - 1u) / kShadeThreads;
     if (blocks == 0u) return hipSuccess;
-    hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, stream, pool, rd, n_init, next_work, out_count);
+    hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(kShadeThreads), 0, stream, pool, rd, n_init, next_work, out_count);
     return hipGetLastError();
 }
 
-hipError_t launch_resolve(const RenderDev& rd, float* out, uint32_t n_local_tiles, hipStream_t stream) {
-    const uint64_t n = (uint64_t)n_local_tiles * rd.tile_size * rd.tile_size;
-    const uint32_t blocks = (uint32_t)((n + 255u) / 256u);
+hipError_t launch_resolve(const RenderDev& rd, float* out, uint32_t n_valid_pixels, hipStream_t stream) {
+    const uint32_t blocks = (n_valid_pixels + 255u) / 256u;
     if (blocks == 0u) return hipSuccess;
-    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, stream, rd, out, n_local_tiles);
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, stream, rd, out);
     return hipGetLastError();
 }
 

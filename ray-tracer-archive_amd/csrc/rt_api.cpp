@@ -42,7 +42,7 @@ struct RtCtx {
     int n_cu = 256;
     std::string err;
     // grow-only work buffers
-    DevBuf pool[2][7]; DevBuf blocksum; DevBuf counters; DevBuf out_tmp;
+    DevBuf pool[2][7]; DevBuf blocksum; DevBuf counters; DevBuf out_tmp; DevBuf tile_prefix;
     uint32_t* h_count = nullptr;                 // pinned
     unsigned long long* h_counters = nullptr;    // pinned
     std::vector<hipEvent_t> events;
@@ -133,7 +133,7 @@ int rt_ctx_destroy(RtCtx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& pl : ctx->pool) for (auto& b : pl) b.release();
-    ctx->blocksum.release(); ctx->counters.release(); ctx->out_tmp.release();
+    ctx->blocksum.release(); ctx->counters.release(); ctx->out_tmp.release(); ctx->tile_prefix.release();
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     if (ctx->h_count) (void)hipHostFree(ctx->h_count);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
@@ -215,18 +215,27 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     rd.width = prm->width; rd.height = prm->height; rd.spp = prm->samples_per_pixel; rd.max_depth = prm->max_depth; rd.seed = prm->seed;
     rd.nan_policy = prm->nan_policy; rd.bg_mode = scene->bg_mode; for (int i = 0; i < 3; ++i) rd.bg[i] = scene->bg[i];
     rd.tile_size = tl.ts; rd.tiles_x = tl.tiles_x; rd.tiles_y = tl.tiles_y; rd.shard_index = si; rd.shard_count = sc;
-    // samples per work item: as small as keeps the item count in 31 bits
-    uint32_t block_len = std::min<uint32_t>(16u, rd.spp);
-    const uint64_t ts2 = (uint64_t)tl.ts * tl.ts;
-    for (;;) {
-        const uint64_t nb = (rd.spp + block_len - 1) / block_len;
-        if ((uint64_t)tl.n_local * nb * ts2 < (1ull << 31) || block_len >= rd.spp) break;
-        block_len *= 2;
+    // in-image pixels per local tile (edge tiles are clipped) -> prefix table
+    std::vector<uint32_t> prefix(tl.n_local + 1, 0u);
+    for (uint32_t lt = 0; lt < tl.n_local; ++lt) {
+        const uint32_t tile = si + lt * sc, tx = tile % tl.tiles_x, ty = tile / tl.tiles_x;
+        const uint32_t w = std::min(tl.ts, prm->width - tx * tl.ts), h = std::min(tl.ts, prm->height - ty * tl.ts);
+        prefix[lt + 1] = prefix[lt] + w * h;
     }
-    rd.block_len = block_len; rd.n_blocks = (rd.spp + block_len - 1) / block_len;
-    const uint64_t total_items = (uint64_t)tl.n_local * rd.n_blocks * ts2;
-    if (total_items >= (1ull << 32)) return set_err(ctx, RT_ERR_INVALID, "too many work items for one shard (image too large)");
+    const uint64_t valid_pixels = prefix[tl.n_local];
+    // samples per work item: a power of two, 16 unless that makes more than 2^31 items
+    uint32_t block_shift = 4;
+    while ((1u << block_shift) > rd.spp && block_shift > 0) --block_shift;
+    for (;;) {
+        const uint64_t nb = (rd.spp + (1u << block_shift) - 1) >> block_shift;
+        if (valid_pixels * nb < (1ull << 31) || (1u << block_shift) >= rd.spp) break;
+        ++block_shift;
+    }
+    rd.block_shift = block_shift; rd.n_blocks = (rd.spp + (1u << block_shift) - 1) >> block_shift;
+    const uint64_t total_items = valid_pixels * rd.n_blocks;
+    if (total_items >= (1ull << 32) - (1ull << 28)) return set_err(ctx, RT_ERR_INVALID, "too many work items for one shard (image too large)");
     rd.total_items = (uint32_t)total_items;
+    rd.n_local_tiles = tl.n_local;
 
     if (stats) { std::memset(stats, 0, sizeof(*stats)); }
     const auto t_begin = clk::now();
@@ -235,21 +244,30 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     uint32_t P = prm->pool_slots ? prm->pool_slots : (1u << 21);
     P = (uint32_t)std::min<uint64_t>(P, total_items);
     P = std::max<uint32_t>(256u, (P + 255u) & ~255u);
-    static const size_t rec[7] = {16, 16, 8, 16, 16, 16, 16};
+    static const size_t rec[7] = {16, 16, 8, 16, 16, 16, 8};
     rtk::PoolDev pd[2];
     for (int k = 0; k < 2; ++k) {
         for (int a = 0; a < 7; ++a) HIP_TRY(ctx, ctx->pool[k][a].ensure((size_t)P * rec[a]));
         pd[k].ray_o = (rtd::Float4*)ctx->pool[k][0].p; pd[k].ray_d = (rtd::Float4*)ctx->pool[k][1].p; pd[k].hit = (uint2*)ctx->pool[k][2].p;
         pd[k].s0 = (rtd::Float4*)ctx->pool[k][3].p; pd[k].s1 = (rtd::Float4*)ctx->pool[k][4].p; pd[k].s2 = (rtd::Float4*)ctx->pool[k][5].p;
-        pd[k].s3 = (rtd::Float4*)ctx->pool[k][6].p;
+        pd[k].s3 = (uint2*)ctx->pool[k][6].p;
     }
     HIP_TRY(ctx, ctx->blocksum.ensure((size_t)total_items * 16));
     rd.blocksum = (rtd::Float4*)ctx->blocksum.p;
-    // counters: [0] next_work, [1] head, [2],[3] pool counts; 64-bit stats from byte 64
-    HIP_TRY(ctx, ctx->counters.ensure(64 + sizeof(unsigned long long) * 16));
-    uint32_t* c32 = (uint32_t*)ctx->counters.p;
-    unsigned long long* c64 = (unsigned long long*)((char*)ctx->counters.p + 64);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, 64 + sizeof(unsigned long long) * 16, ctx->stream));
+    HIP_TRY(ctx, ctx->tile_prefix.ensure(prefix.size() * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->tile_prefix.p, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `prefix` is a stack vector
+    rd.tile_prefix = (const uint32_t*)ctx->tile_prefix.p;
+    // counters, one 128-byte line each (they are hit by atomics from every workgroup):
+    // line 0 next_work, line 1 queue head, lines 2,3 pool counts; 64-bit statistics from line 4
+    constexpr size_t kLine = 128;
+    HIP_TRY(ctx, ctx->counters.ensure(4 * kLine + sizeof(unsigned long long) * 16));
+    char* cbase = (char*)ctx->counters.p;
+    uint32_t* c_next_work = (uint32_t*)(cbase + 0 * kLine);
+    uint32_t* c_head = (uint32_t*)(cbase + 1 * kLine);
+    uint32_t* c_count[2] = {(uint32_t*)(cbase + 2 * kLine), (uint32_t*)(cbase + 3 * kLine)};
+    unsigned long long* c64 = (unsigned long long*)(cbase + 4 * kLine);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, 4 * kLine + sizeof(unsigned long long) * 16, ctx->stream));
 
     const bool counting = (prm->flags & RT_FLAG_COUNTERS) != 0, timing = (prm->flags & RT_FLAG_TIMING) != 0;
     rtk::LaunchCfg cfg{};
@@ -266,25 +284,25 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) HIP_TRY(ctx, next_event(e0));
-    HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, P, &c32[0], &c32[2], ctx->stream));
+    HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, P, c_next_work, c_count[0], ctx->stream));
     if (timing) { HIP_TRY(ctx, next_event(e1)); spans.push_back({e0, e1, 2}); }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count, &c32[2], 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count, c_count[0], 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     uint32_t live = ctx->h_count[0];
     int cur = 0;
     uint32_t iterations = 0; uint64_t segments = 0;
     while (live > 0) {
-        HIP_TRY(ctx, hipMemsetAsync(&c32[1], 0, 4, ctx->stream));              // queue head
-        HIP_TRY(ctx, hipMemsetAsync(&c32[2 + (1 - cur)], 0, 4, ctx->stream));  // output count
+        HIP_TRY(ctx, hipMemsetAsync(c_head, 0, 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(c_count[1 - cur], 0, 4, ctx->stream));
         hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
         if (timing) HIP_TRY(ctx, next_event(ea));
-        HIP_TRY(ctx, rtk::launch_extend(cfg, scene->dev, pd[cur], rd, &c32[2 + cur], &c32[1], c64, counting, ctx->stream));
+        HIP_TRY(ctx, rtk::launch_extend(cfg, scene->dev, pd[cur], rd, c_count[cur], c_head, c64, counting, ctx->stream));
         if (timing) HIP_TRY(ctx, next_event(eb));
-        HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, &c32[2 + cur], &c32[2 + (1 - cur)], &c32[0], c64, counting, ctx->stream));
+        HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, c_count[cur], c_count[1 - cur], c_next_work, c64, counting, ctx->stream));
         if (timing) { HIP_TRY(ctx, next_event(ec)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); }
         segments += live;
         cur = 1 - cur;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count, &c32[2 + cur], 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count, c_count[cur], 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         live = ctx->h_count[0];
         ++iterations;
@@ -292,7 +310,8 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     }
     hipEvent_t r0 = nullptr, r1 = nullptr;
     if (timing) HIP_TRY(ctx, next_event(r0));
-    HIP_TRY(ctx, rtk::launch_resolve(rd, (float*)d_out, tl.n_local, ctx->stream));
+    if (sc > 1) HIP_TRY(ctx, hipMemsetAsync(d_out, 0, (size_t)tl.n_local * tl.ts * tl.ts * 3 * sizeof(float), ctx->stream));   // clipped pixels of edge tiles stay 0
+    HIP_TRY(ctx, rtk::launch_resolve(rd, (float*)d_out, (uint32_t)valid_pixels, ctx->stream));
     if (timing) { HIP_TRY(ctx, next_event(r1)); spans.push_back({r0, r1, 2}); }
     if (counting) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, c64, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -301,12 +320,6 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         for (const Span& s : spans) {
             float ms = 0.f; if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) continue;
             if (s.kind == 0) stats->extend_ms += ms; else if (s.kind == 1) stats->shade_ms += ms; else stats->other_ms += ms;
-        }
-        uint64_t valid_pixels = 0;
-        for (uint32_t lt = 0; lt < tl.n_local; ++lt) {
-            const uint32_t tile = si + lt * sc, tx = tile % tl.tiles_x, ty = tile / tl.tiles_x;
-            const uint32_t w = std::min(tl.ts, prm->width - tx * tl.ts), h = std::min(tl.ts, prm->height - ty * tl.ts);
-            valid_pixels += (uint64_t)w * h;
         }
         stats->samples = valid_pixels * rd.spp;
         stats->segments = segments;

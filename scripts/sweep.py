@@ -1,0 +1,38 @@
+"""Build tuning variants here (CPU), then on the GPU box run each with bench-like timing.
+usage: python scripts/sweep.py build | run"""
+import os, subprocess, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VARIANTS = {
+    "base": [],
+    "c128": ["RT_CHUNK=128"],
+    "c512": ["RT_CHUNK=512"],
+    "s2": ["RT_STEPS=2"],
+    "s8": ["RT_STEPS=8"],
+    "b8": ["RT_LEAF_BATCH=8"],
+    "b24": ["RT_LEAF_BATCH=24"],
+    "b32": ["RT_LEAF_BATCH=32"],
+    "b1": ["RT_LEAF_BATCH=1"],
+}
+if sys.argv[1] == "build":
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("b", os.path.join(ROOT, "ray-tracer-archive_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    from concurrent.futures import ThreadPoolExecutor
+    names = sys.argv[2:] or list(VARIANTS)
+    with ThreadPoolExecutor(4) as ex:
+        for n, p in zip(names, ex.map(lambda n: b.build_variant(n, VARIANTS[n]), names)):
+            print(n, p)
+else:
+    names = sys.argv[2:] or list(VARIANTS)
+    pools = [int(x) for x in os.environ.get("POOLS", "2097152").split(",")]
+    for n in names:
+        for pool in pools:
+            env = dict(os.environ, RT_HIP_LIB=os.path.join(ROOT, "ray-tracer-archive_amd", "lib", "variants", f"librt_hip_{n}.so"))
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--spp", os.environ.get("SPP", "200"),
+                                "--pool-slots", str(pool)], env=env, capture_output=True, text=True)
+            try:
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                print(f"{n:8s} pool {pool:9d}: {j['value']:8.1f} Msamples/s  extend {j['roofline']['extend_ms_per_step']:7.1f} ms shade {j['roofline']['shade_ms_per_step']:6.1f} ms  step {j['ms_per_step']:7.1f} ms", flush=True)
+            except Exception as e:
+                print(n, pool, "FAILED", r.stdout[-300:], r.stderr[-600:], flush=True)
