@@ -200,6 +200,7 @@ typedef struct RtStats {
     uint64_t scene_bytes;     /* device bytes of nodes + primitives */
     uint32_t bvh_in_lds;      /* 1 if the whole node/primitive set is staged in LDS */
     uint32_t _pad;
+    uint64_t debug[8];        /* diagnostic builds only (in-kernel cycle stamps); 0 otherwise */
 } RtStats;
 
 typedef struct RtCtx RtCtx;      /* one per (process, device, stream); not re-entrant */

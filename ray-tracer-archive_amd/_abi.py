@@ -69,7 +69,7 @@ class RtStats(C.Structure):
     _fields_ = [("render_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("other_ms", C.c_double),
                 ("samples", C.c_uint64), ("segments", C.c_uint64), ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64 * RT_N_PRIM_TYPES),
                 ("iterations", C.c_uint32), ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("pool_slots", C.c_uint32),
-                ("scene_nodes", C.c_uint64), ("scene_prims", C.c_uint64), ("scene_bytes", C.c_uint64), ("bvh_in_lds", C.c_uint32), ("_pad", C.c_uint32)]
+                ("scene_nodes", C.c_uint64), ("scene_prims", C.c_uint64), ("scene_bytes", C.c_uint64), ("bvh_in_lds", C.c_uint32), ("_pad", C.c_uint32), ("debug", C.c_uint64 * 8)]
 
     def as_dict(self):
         d = {}

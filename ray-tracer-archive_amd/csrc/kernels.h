@@ -13,7 +13,7 @@ enum : uint32_t {
     F_ALL = 127u
 };
 #define RT_N_PRIM_TYPES_K 6
-enum : uint32_t { CTR_NODE_TESTS = 0, CTR_PRIM_TESTS = 1, CTR_SAMPLES = 7, CTR_COUNT = 8 };
+enum : uint32_t { CTR_NODE_TESTS = 0, CTR_PRIM_TESTS = 1, CTR_SAMPLES = 7, CTR_DEBUG = 8, CTR_SEGMENTS = 13, CTR_ITERATIONS = 14, CTR_COUNT = 16 };
 #define RT_BG_SKY_GRADIENT_K 1
 #define RT_NAN_PER_SAMPLE_K 0u
 
@@ -68,10 +68,13 @@ struct LaunchCfg {
 };
 
 hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_init, uint32_t* next_work, uint32_t* out_count, hipStream_t stream);
+// One wavefront iteration = launch_extend then launch_shade. No memsets in between: k_extend zeroes
+// the count the following k_shade appends to, k_shade zeroes the queue head of the next k_extend.
 hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
-                         uint32_t* head, unsigned long long* counters, bool count, hipStream_t stream);
+                         uint32_t* head, uint32_t* count_out_to_zero, unsigned long long* counters, bool count, hipStream_t stream);
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
-                        const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, unsigned long long* counters, bool count, hipStream_t stream);
+                        const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, uint32_t* head_to_zero, unsigned long long* counters,
+                        bool count, hipStream_t stream);
 hipError_t launch_resolve(const RenderDev& rd, float* out, uint32_t n_valid_pixels, hipStream_t stream);
 hipError_t launch_write_color(const float* rgb_sum, uint32_t n_pixels, uint32_t spp, uint8_t* rgb8, hipStream_t stream);
 

@@ -55,6 +55,7 @@ DEVI V3 refract(V3 uv, V3 n, float eta) {                                    // 
     V3 par = -sqrtf(fabsf(1.0f - len2(perp))) * n;
     return perp + par;
 }
+DEVI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp; rcp(+-0) = +-inf
 DEVI float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kInf = __builtin_huge_valf();
@@ -270,6 +271,14 @@ DEVI bool medium_hit(const SceneDev& sc, const rtd::Medium& m, V3 ow, V3 dw, flo
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 16    // lanes with a pending leaf that trigger a primitive-test pass
 #endif
+#ifndef RT_EXTEND_THREADS
+#define RT_EXTEND_THREADS 256   // workgroup of k_extend: all its waves share one LDS copy of the scene
+#endif
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 16    // idle lanes that trigger a refill (the refill pass runs with only those lanes active)
+#endif
+constexpr int kRefillMin = RT_REFILL_MIN;
+constexpr uint32_t kExtendThreads = RT_EXTEND_THREADS;
 constexpr uint32_t kChunk = RT_CHUNK;
 constexpr int kSteps = RT_STEPS;
 constexpr int kLeafBatch = RT_LEAF_BATCH;
@@ -280,10 +289,11 @@ constexpr int kLeafBatch = RT_LEAF_BATCH;
 // several node visits, and in lock step with node visits it would run with one or two active lanes.
 // Per lane the ORDER of events is unchanged: the leaf is tested before the lane visits its next node.
 template <bool LDS, uint32_t FEAT, bool COUNT>
-__global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
-                                                 uint32_t* __restrict__ head, unsigned long long* __restrict__ counters,
-                                                 RenderDev rd) {
+__global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
+                                                 uint32_t* __restrict__ head, uint32_t* __restrict__ count_out_to_zero,
+                                                 unsigned long long* __restrict__ counters, RenderDev rd) {
     extern __shared__ float4 lds[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out_to_zero = 0u;   // the next k_shade appends to it
     const uint32_t n_nodes = sc.n_nodes;
     const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
     const float4* spheres = reinterpret_cast<const float4*>(sc.spheres);
@@ -307,10 +317,17 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
     uint64_t mkey = 0; uint32_t seg = 0;
     unsigned long long c_nodes = 0, c_prims[RT_N_PRIM_TYPES_K] = {0, 0, 0, 0, 0, 0};
 
+#ifdef RT_STAMPS
+    unsigned long long st_refill = 0, st_node = 0, st_prim = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
+#define STAMP(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(x)
+#endif
     for (;;) {
+        STAMP(st_a);
         // ---- refill: idle lanes take the next rays of this wave's chunk (ballot + prefix rank) ----
         const uint64_t idle = __ballot(!have);
-        if (idle != 0ull && !exhausted) {
+        if (!exhausted && ((int)__popcll(idle) >= kRefillMin || (idle != 0ull && __ballot(have) == 0ull))) {
             uint32_t avail = w_end - w_next;
             if (avail == 0u) {
                 uint32_t start = 0;
@@ -325,7 +342,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
                     slot = w_next + rank;
                     const Float4 ro = pool.ray_o[slot], rdv = pool.ray_d[slot];
                     o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
-                    inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    inv = v3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));   // culling only: boxes carry the slack (scene_compile.cpp)
                     oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
                     a = len2(d);
                     if (FEAT & F_XFORM) { ow = o; dw = d; }
@@ -342,6 +359,10 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
             }
         }
         if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
+#ifdef RT_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        STAMP(st_b); st_refill += st_b - st_a;
+#endif
 
         // ---- node pass ----
 #pragma unroll 1
@@ -368,7 +389,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
                             const uint32_t xf = leaf & rtd::LEAF_MAX_FIRST;
                             if (xf == 0u) { o = ow; d = dw; }
                             else xform_ray(sc.xforms[xf], ow, dw, o, d);
-                            inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                            inv = v3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
                             oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
                             if (COUNT) { if (type == rtd::LT_ENTER) c_prims[5]++; }
                         } else pend = leaf;            // 0 for an inner node
@@ -380,6 +401,10 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
             }
         }
 
+#ifdef RT_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        STAMP(st_a); st_node += st_a - st_b;
+#endif
         // ---- primitive pass: when enough lanes hold a leaf, or nobody can walk any further ----
         const uint64_t pm = __ballot(pend != 0u);
         if (pm == 0ull) continue;
@@ -424,7 +449,17 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, PoolDev pool, const
                 if (medium_hit(sc, m, mo, md, kTMin, tmax, xi, t)) { tmax = t; hit_prim = (rtd::LT_MEDIUM << 28) | first; }
             }
         }
+#ifdef RT_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        STAMP(st_b); st_prim += st_b - st_a;
+#endif
     }
+#ifdef RT_STAMPS
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(&counters[CTR_DEBUG + 0], st_refill); atomicAdd(&counters[CTR_DEBUG + 1], st_node); atomicAdd(&counters[CTR_DEBUG + 2], st_prim);
+        atomicAdd(&counters[CTR_DEBUG + 3], __builtin_amdgcn_s_memtime() - st_t0); atomicAdd(&counters[CTR_DEBUG + 4], 1ull);
+    }
+#endif
     if (COUNT) {
         // one atomic per wave and counter
         for (int off = 32; off > 0; off >>= 1) {
@@ -671,11 +706,16 @@ DEVI void sphere_uv(V3 p, float& u, float& v) {                                /
 
 template <uint32_t FEAT, bool COUNT>
 __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in, PoolDev out, RenderDev rd, const uint32_t* __restrict__ count_in_ptr,
-                                                uint32_t* __restrict__ count_out, uint32_t* __restrict__ next_work,
+                                                uint32_t* __restrict__ count_out, uint32_t* __restrict__ next_work, uint32_t* __restrict__ head_to_zero,
                                                 unsigned long long* __restrict__ counters) {
     __shared__ uint32_t s_scan[kShadeThreads / 64 + 1];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t count_in = *count_in_ptr;
+    if (i == 0u) {
+        *head_to_zero = 0u;                                                   // queue head of the next k_extend
+        atomicAdd(&counters[CTR_SEGMENTS], (unsigned long long)count_in);     // world.hit calls so far
+        if (count_in) atomicAdd(&counters[CTR_ITERATIONS], 1ull);
+    }
     bool alive = i < count_in;
     PathState s{}; V3 o = v3(0, 0, 0), d = v3(0, 0, 1); float tm = 0.f;
     unsigned long long c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
@@ -911,35 +951,36 @@ __global__ void __launch_bounds__(256) k_write_color(const float* __restrict__ r
 // ------------------------------------------------------------------------------------------------
 template <bool LDS, uint32_t FEAT>
 static hipError_t launch_extend_t(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
-                                  uint32_t* head, unsigned long long* counters, bool count, hipStream_t stream) {
+                                  uint32_t* head, uint32_t* cz, unsigned long long* counters, bool count, hipStream_t stream) {
     const size_t lds_bytes = LDS ? ((size_t)sc.n_nodes * 32u + (size_t)sc.n_spheres * 16u) : 0u;
-    if (count) hipLaunchKernelGGL((k_extend<LDS, FEAT, true>), dim3(cfg.extend_blocks), dim3(256), lds_bytes, stream, sc, pool, count_ptr, head, counters, rd);
-    else hipLaunchKernelGGL((k_extend<LDS, FEAT, false>), dim3(cfg.extend_blocks), dim3(256), lds_bytes, stream, sc, pool, count_ptr, head, counters, rd);
+    if (count) hipLaunchKernelGGL((k_extend<LDS, FEAT, true>), dim3(cfg.extend_blocks * 256u / kExtendThreads), dim3(kExtendThreads), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
+    else hipLaunchKernelGGL((k_extend<LDS, FEAT, false>), dim3(cfg.extend_blocks * 256u / kExtendThreads), dim3(kExtendThreads), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
     return hipGetLastError();
 }
 
 hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
-                         uint32_t* head, unsigned long long* counters, bool count, hipStream_t stream) {
+                         uint32_t* head, uint32_t* cz, unsigned long long* counters, bool count, hipStream_t stream) {
     const bool simple = (cfg.features == 0u);
     if (cfg.scene_in_lds) {
-        if (simple) return launch_extend_t<true, 0u>(cfg, sc, pool, rd, count_ptr, head, counters, count, stream);
-        return launch_extend_t<true, F_ALL>(cfg, sc, pool, rd, count_ptr, head, counters, count, stream);
+        if (simple) return launch_extend_t<true, 0u>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream);
+        return launch_extend_t<true, F_ALL>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream);
     }
-    if (simple) return launch_extend_t<false, 0u>(cfg, sc, pool, rd, count_ptr, head, counters, count, stream);
-    return launch_extend_t<false, F_ALL>(cfg, sc, pool, rd, count_ptr, head, counters, count, stream);
+    if (simple) return launch_extend_t<false, 0u>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream);
+    return launch_extend_t<false, F_ALL>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream);
 }
 
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
-                        const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, unsigned long long* counters, bool count, hipStream_t stream) {
+                        const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, uint32_t* hz, unsigned long long* counters, bool count,
+                        hipStream_t stream) {
     const uint32_t blocks = (max_count + kShadeThreads - 1u) / kShadeThreads;
     if (blocks == 0u) return hipSuccess;
     const bool simple = (cfg.features == 0u);
     if (simple) {
-        if (count) hipLaunchKernelGGL((k_shade<0u, true>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
-        else hipLaunchKernelGGL((k_shade<0u, false>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
+        if (count) hipLaunchKernelGGL((k_shade<0u, true>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
+        else hipLaunchKernelGGL((k_shade<0u, false>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
     } else {
-        if (count) hipLaunchKernelGGL((k_shade<F_ALL, true>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
-        else hipLaunchKernelGGL((k_shade<F_ALL, false>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, counters);
+        if (count) hipLaunchKernelGGL((k_shade<F_ALL, true>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
+        else hipLaunchKernelGGL((k_shade<F_ALL, false>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
     }
     return hipGetLastError();
 }

@@ -241,7 +241,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     const auto t_begin = clk::now();
     if (total_items == 0) { if (stats) stats->render_ms = 0.0; return RT_OK; }
 
-    uint32_t P = prm->pool_slots ? prm->pool_slots : (1u << 21);
+    uint32_t P = prm->pool_slots ? prm->pool_slots : (1u << 24);   // rays per launch >> resident lanes, so persistent waves stay fed
     P = (uint32_t)std::min<uint64_t>(P, total_items);
     P = std::max<uint32_t>(256u, (P + 255u) & ~255u);
     static const size_t rec[7] = {16, 16, 8, 16, 16, 16, 8};
@@ -288,32 +288,35 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     if (timing) { HIP_TRY(ctx, next_event(e1)); spans.push_back({e0, e1, 2}); }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count, c_count[0], 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    uint32_t live = ctx->h_count[0];
+    uint32_t live = ctx->h_count[0];   // upper bound of the pool's size from here on: it never grows
     int cur = 0;
-    uint32_t iterations = 0; uint64_t segments = 0;
+    // Iterations are enqueued in batches without touching the host: the kernels read the pool size
+    // from device memory and size-check themselves, so only termination needs a round trip.
+    uint32_t batch = 4, launched = 0;
     while (live > 0) {
-        HIP_TRY(ctx, hipMemsetAsync(c_head, 0, 4, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(c_count[1 - cur], 0, 4, ctx->stream));
-        hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
-        if (timing) HIP_TRY(ctx, next_event(ea));
-        HIP_TRY(ctx, rtk::launch_extend(cfg, scene->dev, pd[cur], rd, c_count[cur], c_head, c64, counting, ctx->stream));
-        if (timing) HIP_TRY(ctx, next_event(eb));
-        HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, c_count[cur], c_count[1 - cur], c_next_work, c64, counting, ctx->stream));
-        if (timing) { HIP_TRY(ctx, next_event(ec)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); }
-        segments += live;
-        cur = 1 - cur;
+        for (uint32_t k = 0; k < batch; ++k) {
+            hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
+            if (timing) HIP_TRY(ctx, next_event(ea));
+            HIP_TRY(ctx, rtk::launch_extend(cfg, scene->dev, pd[cur], rd, c_count[cur], c_head, c_count[1 - cur], c64, counting, ctx->stream));
+            if (timing) HIP_TRY(ctx, next_event(eb));
+            HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, c_count[cur], c_count[1 - cur], c_next_work, c_head, c64, counting,
+                                           ctx->stream));
+            if (timing) { HIP_TRY(ctx, next_event(ec)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); }
+            cur = 1 - cur;
+            ++launched;
+        }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count, c_count[cur], 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         live = ctx->h_count[0];
-        ++iterations;
-        if (iterations > 100000000u) return set_err(ctx, RT_ERR_DEVICE, "render loop did not terminate");
+        if (batch < 32) batch *= 2;
+        if (launched > 100000000u) return set_err(ctx, RT_ERR_DEVICE, "render loop did not terminate");
     }
     hipEvent_t r0 = nullptr, r1 = nullptr;
     if (timing) HIP_TRY(ctx, next_event(r0));
     if (sc > 1) HIP_TRY(ctx, hipMemsetAsync(d_out, 0, (size_t)tl.n_local * tl.ts * tl.ts * 3 * sizeof(float), ctx->stream));   // clipped pixels of edge tiles stay 0
     HIP_TRY(ctx, rtk::launch_resolve(rd, (float*)d_out, (uint32_t)valid_pixels, ctx->stream));
     if (timing) { HIP_TRY(ctx, next_event(r1)); spans.push_back({r0, r1, 2}); }
-    if (counting) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, c64, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, c64, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (stats) {
         stats->render_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
@@ -322,12 +325,13 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
             if (s.kind == 0) stats->extend_ms += ms; else if (s.kind == 1) stats->shade_ms += ms; else stats->other_ms += ms;
         }
         stats->samples = valid_pixels * rd.spp;
-        stats->segments = segments;
+        stats->segments = ctx->h_counters[rtk::CTR_SEGMENTS];
         if (counting) {
             stats->node_tests = ctx->h_counters[rtk::CTR_NODE_TESTS];
             for (int k = 0; k < RT_N_PRIM_TYPES; ++k) stats->prim_tests[k] = ctx->h_counters[rtk::CTR_PRIM_TESTS + k];
         }
-        stats->iterations = iterations; stats->extend_launches = iterations; stats->shade_launches = iterations; stats->pool_slots = P;
+        for (int k = 0; k < 5; ++k) stats->debug[k] = ctx->h_counters[rtk::CTR_DEBUG + k];
+        stats->iterations = (uint32_t)ctx->h_counters[rtk::CTR_ITERATIONS]; stats->extend_launches = launched; stats->shade_launches = launched; stats->pool_slots = P;
         stats->scene_nodes = scene->n_nodes; stats->scene_prims = scene->n_prims; stats->scene_bytes = scene->bytes; stats->bvh_in_lds = scene->in_lds ? 1u : 0u;
     }
     return RT_OK;

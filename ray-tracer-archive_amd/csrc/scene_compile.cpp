@@ -58,6 +58,7 @@ struct Compiler {
     const RtSceneDesc& d;
     CompiledScene& out;
     std::map<std::pair<long long, std::pair<long long, std::pair<long long, long long>>>, uint32_t> xform_cache;
+    double pad_scale = 0.0;   // largest |coordinate| of the world's bounding box
 
     Compiler(const RtSceneDesc& desc, CompiledScene& o) : d(desc), out(o) {}
 
@@ -329,8 +330,15 @@ struct Compiler {
         }
         rtd::Node& n = out.nodes[me];
         // boxes live in the space the children are traversed in; children under an instance
-        // transform are traversed in local space, where the reference's boxes are defined too
-        for (int i = 0; i < 3; ++i) { n.mn[i] = f_down(box.mn[i]); n.mx[i] = f_up(box.mx[i]); }
+        // transform are traversed in local space, where the reference's boxes are defined too.
+        // The device slab test evaluates fma(bound, 1/d, -o/d) with a 1-ulp reciprocal: its absolute
+        // error is a few 1e-7 * (|bound| + |o|) / |d|, so each bound moves outwards by that much with
+        // |o| <= scene extent (pad_scale, set by compile_scene). A BVH only culls: a looser box
+        // costs visits, never a hit.
+        for (int i = 0; i < 3; ++i) {
+            n.mn[i] = f_down(box.mn[i] - 1e-6 * (std::fabs(box.mn[i]) + pad_scale));
+            n.mx[i] = f_up(box.mx[i] + 1e-6 * (std::fabs(box.mx[i]) + pad_scale));
+        }
         n.leaf = 0;
         n.skip = (uint32_t)out.nodes.size();
         return box;
@@ -479,6 +487,12 @@ int compile_scene(const RtSceneDesc& desc, CompiledScene& out) {
     out.xforms.push_back(rtd::Xform{0.f, 1.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
     c.compile_materials();
     if (!c.ok()) return RT_ERR_INVALID;
+    {
+        Box3 wb;
+        if (c.bbox(desc.world, 0.0, 1.0, wb)) for (int i = 0; i < 3; ++i) c.pad_scale = std::max(c.pad_scale, std::max(std::fabs(wb.mn[i]), std::fabs(wb.mx[i])));
+        if (!std::isfinite(c.pad_scale)) c.pad_scale = 0.0;
+        out.error.clear();   // a world without a box (empty list) is legal for a LIST root
+    }
     Chain root;
     c.emit(desc.world, root);
     if (!c.ok()) return out.error.find("must be") != std::string::npos ? RT_ERR_UNSUPPORTED : RT_ERR_INVALID;

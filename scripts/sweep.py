@@ -5,6 +5,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {
     "base": [],
+    "stamps": ["RT_STAMPS=1"],
+    "r1": ["RT_REFILL_MIN=1"],
+    "r8": ["RT_REFILL_MIN=8"],
+    "r24": ["RT_REFILL_MIN=24"],
+    "r32": ["RT_REFILL_MIN=32"],
+    "r48": ["RT_REFILL_MIN=48"],
+    "t512": ["RT_EXTEND_THREADS=512"],
+    "t1024": ["RT_EXTEND_THREADS=1024"],
     "c128": ["RT_CHUNK=128"],
     "c512": ["RT_CHUNK=512"],
     "s2": ["RT_STEPS=2"],
@@ -25,7 +33,7 @@ if sys.argv[1] == "build":
             print(n, p)
 else:
     names = sys.argv[2:] or list(VARIANTS)
-    pools = [int(x) for x in os.environ.get("POOLS", "2097152").split(",")]
+    pools = [int(x) for x in os.environ.get("POOLS", "16777216").split(",")]
     for n in names:
         for pool in pools:
             env = dict(os.environ, RT_HIP_LIB=os.path.join(ROOT, "ray-tracer-archive_amd", "lib", "variants", f"librt_hip_{n}.so"))
