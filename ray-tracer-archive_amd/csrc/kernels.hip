@@ -364,43 +364,44 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
         STAMP(st_b); st_refill += st_b - st_a;
 #endif
 
-        // ---- node pass ----
-#pragma unroll 1
+        // ---- node pass: branch-free steps. A lane that is not walking (no ray, holding a leaf, or past the
+        // last node) re-reads node 0 and keeps its state; everything is a select, so a step is ~30 VALU, two
+        // ds_read_b128 and no exec-mask traffic. ----
+#pragma unroll
         for (int step = 0; step < kSteps; ++step) {
-            if (have && pend == 0u) {
-                if (node >= n_nodes) {
-                    pool.hit[slot] = make_uint2(__float_as_uint(tmax), hit_prim);
-                    have = false;
-                } else {
-                    const float4 n0 = nodes[2 * node], n1 = nodes[2 * node + 1];
-                    const uint32_t skip = __float_as_uint(n0.w), leaf = __float_as_uint(n1.w);
-                    // Aabb::hit (aabb.rs:31-55, interval carried across axes). min/max ignore a NaN
-                    // operand (0*inf), which keeps the box — conservative, like the reference.
-                    const float tx0 = fmaf(n0.x, inv.x, -oi.x), tx1 = fmaf(n1.x, inv.x, -oi.x);
-                    const float ty0 = fmaf(n0.y, inv.y, -oi.y), ty1 = fmaf(n1.y, inv.y, -oi.y);
-                    const float tz0 = fmaf(n0.z, inv.z, -oi.z), tz1 = fmaf(n1.z, inv.z, -oi.z);
-                    const float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), kTMin));
-                    const float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
-                    const bool boxhit = tnear <= tfar * 1.0000004f;   // padded by 3 ulp: never cull a true hit
-                    if (COUNT) { if (n0.x > -kInf) c_nodes++; }
-                    if (boxhit) {
-                        const uint32_t type = leaf >> 28;
-                        if ((FEAT & F_XFORM) && (type == rtd::LT_ENTER || type == rtd::LT_EXIT)) {
-                            const uint32_t xf = leaf & rtd::LEAF_MAX_FIRST;
-                            if (xf == 0u) { o = ow; d = dw; }
-                            else xform_ray(sc.xforms[xf], ow, dw, o, d);
-                            inv = v3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
-                            oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
-                            if (COUNT) { if (type == rtd::LT_ENTER) c_prims[5]++; }
-                        } else pend = leaf;            // 0 for an inner node
-                        node = node + 1u;
-                    } else {
-                        node = skip;
-                    }
-                }
+            const bool walk = have && pend == 0u && node < n_nodes;
+            const uint32_t idx = walk ? node : 0u;
+            const float4 n0 = nodes[2 * idx], n1 = nodes[2 * idx + 1];
+            const uint32_t skip = __float_as_uint(n0.w), leaf = __float_as_uint(n1.w);
+            // Aabb::hit (aabb.rs:31-55, interval carried across axes). min/max ignore a NaN
+            // operand (0*inf), which keeps the box — conservative, like the reference.
+            const float tx0 = fmaf(n0.x, inv.x, -oi.x), tx1 = fmaf(n1.x, inv.x, -oi.x);
+            const float ty0 = fmaf(n0.y, inv.y, -oi.y), ty1 = fmaf(n1.y, inv.y, -oi.y);
+            const float tz0 = fmaf(n0.z, inv.z, -oi.z), tz1 = fmaf(n1.z, inv.z, -oi.z);
+            const float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), kTMin));
+            const float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+            const bool boxhit = tnear <= tfar * 1.0000004f;   // padded by 3 ulp: never cull a true hit
+            if (COUNT) c_nodes += (walk && n0.x > -kInf) ? 1ull : 0ull;
+            node = walk ? (boxhit ? node + 1u : skip) : node;
+            pend = (walk && boxhit) ? leaf : pend;            // leaf == 0 for an inner node
+        }
+        // ---- rare events, outside the steps ----
+        if (have && pend == 0u && node >= n_nodes) {          // walked off the end: world.hit is done
+            pool.hit[slot] = make_uint2(__float_as_uint(tmax), hit_prim);
+            have = false;
+        }
+        if (FEAT & F_XFORM) {
+            const uint32_t type = pend >> 28;
+            if (type == rtd::LT_ENTER || type == rtd::LT_EXIT) {   // Translate/RotateY::hit: switch ray space
+                const uint32_t xf = pend & rtd::LEAF_MAX_FIRST;
+                if (xf == 0u) { o = ow; d = dw; }
+                else xform_ray(sc.xforms[xf], ow, dw, o, d);
+                inv = v3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+                oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+                if (COUNT) { if (type == rtd::LT_ENTER) c_prims[5]++; }
+                pend = 0u;
             }
         }
-
 #ifdef RT_STAMPS
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         STAMP(st_a); st_node += st_a - st_b;

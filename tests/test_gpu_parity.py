@@ -41,7 +41,7 @@ def test_book1_same_seed_vs_f64_oracle(pkg, orc, gpu, book1):
     assert abs(st["segments"] - ost["segments"]) / ost["segments"] < 2e-3
     # device boxes are inflated by ~1e-6 * scene extent (they absorb the slab test's rounding): a few 0.1 % more visits
     assert 0 <= (st["node_tests"] - ost["node_tests"]) / ost["node_tests"] < 1e-2
-    assert abs(st["prim_tests"][0] - ost["prim_tests"][0]) / ost["prim_tests"][0] < 2e-3
+    assert 0 <= (st["prim_tests"][0] - ost["prim_tests"][0]) / ost["prim_tests"][0] < 2e-2
     assert st["bvh_in_lds"] == 1
 
 
