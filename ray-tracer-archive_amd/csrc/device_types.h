@@ -38,11 +38,23 @@ inline uint32_t make_leaf(uint32_t type, uint32_t first, uint32_t count) { retur
 // node is not counted as an Aabb::hit.
 
 // ---- primitives: one geometry array per type (16-byte records) + one u32 `meta` per primitive ----
-// meta = material id (22 bits) | ff_mode << 22 | xform id << 24
-// ff_mode: what the wrappers above the primitive do to HitRecord::front_face (hittable.rs:82-83,
-// 173, 199): 0 keep, 1 negate (FlipFace), 2 force true (Translate/RotateY), 3 force false.
+// meta = material id (22 bits) | wrap id << 22 (10 bits)
+// A "wrap" is the chain of Translate / RotateY / FlipFace objects above the primitive (hittable.rs:62-205).
+// Each of them post-processes the HitRecord on the way out: Translate and RotateY call set_face_normal
+// again (hittable.rs:82-83, 173) — RotateY with the ray of its CHILD space against the normal it has
+// just rotated back to its PARENT space, which can flip the normal — and FlipFace negates front_face
+// (hittable.rs:199). k_shade replays that sequence op by op; wrap 0 = no wrappers.
 constexpr uint32_t META_MAT_MASK = (1u << 22) - 1;
-inline uint32_t make_meta(uint32_t mat, uint32_t ff_mode, uint32_t xform) { return (mat & META_MAT_MASK) | (ff_mode << 22) | (xform << 24); }
+constexpr uint32_t MAX_WRAPS = 1u << 10;
+inline uint32_t make_meta(uint32_t mat, uint32_t wrap) { return (mat & META_MAT_MASK) | (wrap << 22); }
+enum WrapOp : uint32_t { WO_TRANSLATE = 0, WO_ROTATE_Y = 1, WO_FLIP_FACE = 2 };
+constexpr uint32_t MAX_WRAP_OPS = 6;
+struct Wrap {
+    uint32_t xform;      // composite transform of the chain (0 = identity)
+    uint32_t n_ops;      // ops[0] is the outermost wrapper
+    uint32_t _pad[2];
+    struct { uint32_t kind; float sin_t, cos_t; uint32_t _p; } op[MAX_WRAP_OPS];
+};
 
 struct Float4 { float x, y, z, w; };
 // sphere   : 1 x Float4  (center.xyz, radius)                                   sphere.rs:11-15

@@ -25,6 +25,7 @@ struct SceneDev {
     const rtd::Float4* tris; const uint32_t* tri_meta;
     const rtd::Medium* media;
     const rtd::Xform* xforms;
+    const rtd::Wrap* wraps;
     const rtd::Float4* mat_a; const uint32_t* mat_b;
     const rtd::Texture* textures;
     const rtd::PerlinTable* perlins;

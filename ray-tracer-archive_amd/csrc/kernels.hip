@@ -186,6 +186,19 @@ DEVI bool sphere_hit(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax,
     if (sphere_certain_miss(o, d, a, c, r)) return false;
     return sphere_roots(o, d, a, c, r, tmin, tmax, t);
 }
+// The sphere the ray STARTS on (its origin is a hit point of this sphere). In exact arithmetic one root
+// is 0 and is rejected by t_min; the other, -2*half_b/a, is a real hit only when the ray heads inwards.
+// In f32 the origin is off the surface by ~1e-7*|coordinates|, which moves the ~0 root to +-delta/cos
+// and past t_min = 0.001 at grazing exits — and one such false hit traps a diffuse path INSIDE the
+// sphere for the rest of its 50 bounces. So for this one primitive the ~0 root is dropped by
+// construction, which is what the f64 reference computes.
+DEVI bool sphere_hit_from_surface(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax, float& t) {
+    const V3 oc = o - c;
+    const float root = -2.0f * dot(oc, d) / a;
+    if (root < tmin || tmax < root) return false;
+    t = root;
+    return true;
+}
 DEVI V3 moving_center(Float4 m0, Float4 m1, Float4 m2, float time) {           // moving_sphere.rs:36-39
     const float f = (time - m1.w) / (m2.x - m1.w);
     return v3(m0.x + f * (m1.x - m0.x), m0.y + f * (m1.y - m0.y), m0.z + f * (m1.z - m0.z));
@@ -246,7 +259,9 @@ DEVI bool medium_hit(const SceneDev& sc, const rtd::Medium& m, V3 ow, V3 dw, flo
     const float a = len2(d);
     float t1, t2;
     if (!boundary_hit(sc, m, o, d, a, -kInf, kInf, t1)) return false;
-    if (!boundary_hit(sc, m, o, d, a, t1 + 0.0001f, kInf, t2)) return false;
+    // constant_medium.rs:37 searches from rec1.t + 0.0001; in f32 that increment vanishes once |t1| > 2048
+    // (ulp 2.4e-4) and the probe would find the same root again, so the bound is made strictly larger than t1
+    if (!boundary_hit(sc, m, o, d, a, fmaxf(t1 + 0.0001f, nextafterf(t1, kInf)), kInf, t2)) return false;
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
@@ -310,7 +325,7 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
     bool exhausted = false;
 
     bool have = false;
-    uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE, pend = 0;
+    uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE, pend = 0, from = 0;
     float tmax = kInf, tm = 0.f, a = 1.f;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0), oi = v3(0, 0, 0);
     V3 ow = o, dw = d;                 // world ray while inside an instance transform
@@ -342,6 +357,7 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
                     slot = w_next + rank;
                     const Float4 ro = pool.ray_o[slot], rdv = pool.ray_d[slot];
                     o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
+                    from = __float_as_uint(rdv.w);            // primitive this ray starts on (0: camera / medium)
                     inv = v3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));   // culling only: boxes carry the slack (scene_compile.cpp)
                     oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
                     a = len2(d);
@@ -418,28 +434,38 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
                     const float4 s = spheres[first + k];
                     float t;
                     if (COUNT) c_prims[0]++;
-                    if (sphere_hit(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t)) { tmax = t; hit_prim = (rtd::LT_SPHERE << 28) | (first + k); }
+                    const uint32_t id = (rtd::LT_SPHERE << 28) | (first + k);
+                    const bool h = (id == from) ? sphere_hit_from_surface(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t)
+                                                : sphere_hit(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t);
+                    if (h) { tmax = t; hit_prim = id; }
                 }
             } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const Float4 r0 = sc.rects[2 * (first + k)], r1 = sc.rects[2 * (first + k) + 1];
                     float t, ha, hb;
                     if (COUNT) c_prims[2]++;
-                    if (rect_hit(o, d, r0, r1, kTMin, tmax, t, ha, hb)) { tmax = t; hit_prim = (rtd::LT_RECT << 28) | (first + k); }
+                    const uint32_t id = (rtd::LT_RECT << 28) | (first + k);
+                    // a ray that starts on this rect's plane meets it at t = 0 < t_min exactly; in f32 (after an
+                    // instance transform's round trip) t = rounding / d_k can pass t_min
+                    if (id != from && rect_hit(o, d, r0, r1, kTMin, tmax, t, ha, hb)) { tmax = t; hit_prim = id; }
                 }
             } else if ((FEAT & F_MOVING) && type == rtd::LT_MOVING) {
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const Float4 m0 = sc.moving[3 * (first + k)], m1 = sc.moving[3 * (first + k) + 1], m2 = sc.moving[3 * (first + k) + 2];
                     float t;
                     if (COUNT) c_prims[1]++;
-                    if (sphere_hit(o, d, a, moving_center(m0, m1, m2, tm), m0.w, kTMin, tmax, t)) { tmax = t; hit_prim = (rtd::LT_MOVING << 28) | (first + k); }
+                    const uint32_t id = (rtd::LT_MOVING << 28) | (first + k);
+                    const V3 mc = moving_center(m0, m1, m2, tm);
+                    const bool h = (id == from) ? sphere_hit_from_surface(o, d, a, mc, m0.w, kTMin, tmax, t) : sphere_hit(o, d, a, mc, m0.w, kTMin, tmax, t);
+                    if (h) { tmax = t; hit_prim = id; }
                 }
             } else if ((FEAT & F_TRI) && type == rtd::LT_TRI) {
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const Float4 t0 = sc.tris[3 * (first + k)], t1 = sc.tris[3 * (first + k) + 1], t2 = sc.tris[3 * (first + k) + 2];
                     float t, bu, bv;
                     if (COUNT) c_prims[3]++;
-                    if (tri_hit(o, d, f4xyz(t0), f4xyz(t1), f4xyz(t2), kTMin, tmax, t, bu, bv)) { tmax = t; hit_prim = (rtd::LT_TRI << 28) | (first + k); }
+                    const uint32_t id = (rtd::LT_TRI << 28) | (first + k);
+                    if (id != from && tri_hit(o, d, f4xyz(t0), f4xyz(t1), f4xyz(t2), kTMin, tmax, t, bu, bv)) { tmax = t; hit_prim = id; }
                 }
             } else if ((FEAT & F_MEDIUM) && type == rtd::LT_MEDIUM) {
                 const rtd::Medium m = sc.media[first];
@@ -547,11 +573,12 @@ DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t s
 struct PathState {
     V3 T, L, acc;
     uint32_t work, sdepth, xy;   // sdepth = sample index << 8 | depth;  xy = x | y << 16
+    uint32_t from;               // primitive id the ray starts on (hit-record id), 0 = none
     uint64_t rng;
 };
 DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const PathState& s) {
     p.ray_o[i] = Float4{o.x, o.y, o.z, tm};
-    p.ray_d[i] = Float4{d.x, d.y, d.z, 0.f};
+    p.ray_d[i] = Float4{d.x, d.y, d.z, __uint_as_float(s.from)};
     p.s0[i] = Float4{s.T.x, s.T.y, s.T.z, s.L.x};
     p.s1[i] = Float4{s.L.y, s.L.z, s.acc.x, s.acc.y};
     p.s2[i] = Float4{s.acc.z, __uint_as_float(s.work), __uint_as_float(s.sdepth), __uint_as_float(s.xy)};
@@ -584,7 +611,7 @@ DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, V3& o, V3
     const uint32_t sample = it.blk << rd.block_shift;
     new_camera_ray(rd, it.x, it.y, sample, g, o, d, tm);
     s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); s.acc = v3(0, 0, 0);
-    s.work = work; s.sdepth = sample << 8; s.xy = it.x | (it.y << 16); s.rng = g.s;
+    s.work = work; s.sdepth = sample << 8; s.xy = it.x | (it.y << 16); s.rng = g.s; s.from = 0u;
 }
 
 __global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, RenderDev rd, uint32_t n_init, uint32_t* __restrict__ next_work, uint32_t* __restrict__ out_count) {
@@ -756,7 +783,10 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
                      : ((FEAT & F_RECT) && type == rtd::LT_RECT) ? sc.rect_meta[idx]
                      : ((FEAT & F_MOVING) && type == rtd::LT_MOVING) ? sc.moving_meta[idx]
                      : ((FEAT & F_TRI) && type == rtd::LT_TRI) ? sc.tri_meta[idx] : 0u;
-                const uint32_t xf = (FEAT & F_XFORM) ? (meta >> 24) : 0u;
+                const uint32_t wrap = (FEAT & F_XFORM) ? (meta >> 22) : 0u;
+                rtd::Wrap W{};
+                if ((FEAT & F_XFORM) && wrap) W = sc.wraps[wrap];
+                const uint32_t xf = W.xform;
                 V3 ol = o, dl = d;
                 if ((FEAT & F_XFORM) && xf) xform_ray(sc.xforms[xf], o, d, ol, dl);
                 V3 outward;
@@ -788,13 +818,41 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
                 }
                 ff = dot(dl, outward) < 0.f;                                    // set_face_normal, hittable.rs:41-48
                 n = ff ? outward : -outward;
-                if ((FEAT & F_XFORM) && xf) { p = xform_point_back(sc.xforms[xf], p); n = xform_normal_back(sc.xforms[xf], n); }
-                const uint32_t ffm = (meta >> 22) & 3u;                         // wrappers above the primitive
-                ff = ffm == 0u ? ff : (ffm == 1u ? !ff : (ffm == 2u));
+                if ((FEAT & F_XFORM) && wrap) {
+                    if (xf) p = xform_point_back(sc.xforms[xf], p);
+                    // Replay the wrappers from the innermost out. dirs: the ray direction each wrapper hands to
+                    // its child (Translate keeps it, RotateY rotates it, hittable.rs:154-155).
+                    V3 dk[rtd::MAX_WRAP_OPS + 1];
+                    dk[0] = d;
+#pragma unroll
+                    for (uint32_t k = 0; k < rtd::MAX_WRAP_OPS; ++k) {
+                        const float sn = W.op[k].sin_t, cs = W.op[k].cos_t;
+                        const V3 q = dk[k];
+                        dk[k + 1] = (k < W.n_ops && W.op[k].kind == rtd::WO_ROTATE_Y) ? v3(cs * q.x - sn * q.z, q.y, sn * q.x + cs * q.z) : q;
+                    }
+#pragma unroll
+                    for (int k = (int)rtd::MAX_WRAP_OPS - 1; k >= 0; --k) {
+                        if ((uint32_t)k < W.n_ops) {
+                            const uint32_t kind = W.op[k].kind;
+                            if (kind == rtd::WO_FLIP_FACE) ff = !ff;                                   // hittable.rs:199
+                            else {
+                                if (kind == rtd::WO_ROTATE_Y) {                                        // hittable.rs:169-170
+                                    const float sn = W.op[k].sin_t, cs = W.op[k].cos_t;
+                                    n = v3(cs * n.x + sn * n.z, n.y, -sn * n.x + cs * n.z);
+                                }
+                                ff = dot(dk[k + 1], n) < 0.f;                                          // hittable.rs:82-83 / 173
+                                n = ff ? n : -n;
+                            }
+                        }
+                    }
+                }
             }
             const uint32_t mat = meta & rtd::META_MAT_MASK;
             const Float4 ma = sc.mat_a[mat]; const uint32_t mb = sc.mat_b[mat];
             const uint32_t kind = mb & 15u, tex = mb >> 4;
+            // the next ray starts on this primitive (not for a medium: its hit point is inside the volume; not for a
+            // Metal bounce off a moving sphere: Metal resets the ray's time to 0, which moves the sphere)
+            s.from = (type == rtd::LT_MEDIUM || (type == rtd::LT_MOVING && kind == rtd::MK_METAL)) ? 0u : hit.y;
             V3 colour = v3(ma.x, ma.y, ma.z);
             if ((FEAT & F_TEX) && tex != rtd::TEX_INLINE && kind != rtd::MK_METAL && kind != rtd::MK_DIELECTRIC) colour = texture_value(sc, tex, hu, hv, p);
 
@@ -877,7 +935,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
             sample++;
             if ((sample & ((1u << rd.block_shift) - 1u)) != 0u && sample < rd.spp) {
                 new_camera_ray(rd, s.xy & 0xFFFFu, s.xy >> 16, sample, g, o, d, tm);   // next sample of the same block
-                s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); depth = 0;
+                s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); depth = 0; s.from = 0u;
             } else {
                 rd.blocksum[s.work] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
                 want_work = true;

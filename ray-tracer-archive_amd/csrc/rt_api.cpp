@@ -49,7 +49,7 @@ struct RtCtx {
 };
 
 struct RtScene {
-    DevBuf nodes, spheres, sphere_meta, moving, moving_meta, rects, rect_meta, tris, tri_meta, media, xforms, mat_a, mat_b, textures, perlins, images,
+    DevBuf nodes, spheres, sphere_meta, moving, moving_meta, rects, rect_meta, tris, tri_meta, media, xforms, wraps, mat_a, mat_b, textures, perlins, images,
         image_bytes, lights;
     rtk::SceneDev dev{};
     uint32_t features = 0; bool in_lds = false;
@@ -155,7 +155,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     auto up = [&](auto& buf, const auto& vec) { if (r == RT_OK) r = upload(ctx, buf, vec); };
     up(s->nodes, cs.nodes); up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
     up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->media, cs.media);
-    up(s->xforms, cs.xforms); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
+    up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
     up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
     if (r == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = set_err(ctx, RT_ERR_DEVICE, "scene upload failed");
     if (r != RT_OK) { rt_scene_destroy(ctx, s); return r; }
@@ -165,7 +165,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     d.moving = (const rtd::Float4*)s->moving.p; d.moving_meta = (const uint32_t*)s->moving_meta.p;
     d.rects = (const rtd::Float4*)s->rects.p; d.rect_meta = (const uint32_t*)s->rect_meta.p;
     d.tris = (const rtd::Float4*)s->tris.p; d.tri_meta = (const uint32_t*)s->tri_meta.p;
-    d.media = (const rtd::Medium*)s->media.p; d.xforms = (const rtd::Xform*)s->xforms.p;
+    d.media = (const rtd::Medium*)s->media.p; d.xforms = (const rtd::Xform*)s->xforms.p; d.wraps = (const rtd::Wrap*)s->wraps.p;
     d.mat_a = (const rtd::Float4*)s->mat_a.p; d.mat_b = (const uint32_t*)s->mat_b.p;
     d.textures = (const rtd::Texture*)s->textures.p; d.perlins = (const rtd::PerlinTable*)s->perlins.p;
     d.images = (const rtd::Image*)s->images.p; d.image_bytes = (const uint8_t*)s->image_bytes.p;
@@ -187,7 +187,7 @@ int rt_scene_destroy(RtCtx* ctx, RtScene* s) {
     if (!s) return RT_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     DevBuf* all[] = {&s->nodes, &s->spheres, &s->sphere_meta, &s->moving, &s->moving_meta, &s->rects, &s->rect_meta, &s->tris, &s->tri_meta, &s->media,
-                     &s->xforms, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights};
+                     &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights};
     for (DevBuf* b : all) b->release();
     delete s;
     return RT_OK;
@@ -390,7 +390,7 @@ static uint32_t scene_features(const rtc::CompiledScene& cs) {
     if (!cs.rect_meta.empty()) f |= rtk::F_RECT;
     if (!cs.tri_meta.empty()) f |= rtk::F_TRI;
     if (!cs.media.empty()) f |= rtk::F_MEDIUM;
-    if (cs.xforms.size() > 1) f |= rtk::F_XFORM;
+    if (cs.xforms.size() > 1 || cs.wraps.size() > 1) f |= rtk::F_XFORM;
     for (uint32_t mb : cs.mat_b) { const uint32_t kind = mb & 15u; if ((mb >> 4) != rtd::TEX_INLINE && kind != rtd::MK_METAL && kind != rtd::MK_DIELECTRIC) f |= rtk::F_TEX; }
     if (cs.has_lights) f |= rtk::F_LIGHTS;
     return f;

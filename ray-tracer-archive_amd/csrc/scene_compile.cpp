@@ -37,19 +37,10 @@ struct Chain {
     double theta = 0.0;            // radians, sum of the RotateY angles
     double off[3] = {0, 0, 0};
     bool identity = true;
-    std::vector<char> ops;         // outer -> inner: 'W' translate/rotate, 'F' flip-face
+    struct Op { uint32_t kind; double degrees; };
+    std::vector<Op> ops;           // outer -> inner: every Translate / RotateY / FlipFace above the primitive
     uint32_t xform_id = 0;         // id of (theta, off) in CompiledScene::xforms
 };
-
-inline uint32_t fold_ff_mode(const std::vector<char>& ops) {
-    // inner -> outer: W forces front_face = true (hittable.rs:82-83,173), F negates it (hittable.rs:199)
-    int mode = 0;   // 0 keep, 1 negate, 2 true, 3 false
-    for (auto it = ops.rbegin(); it != ops.rend(); ++it) {
-        if (*it == 'W') mode = 2;
-        else mode = (mode == 0) ? 1 : (mode == 1) ? 0 : (mode == 2) ? 3 : 2;
-    }
-    return (uint32_t)mode;
-}
 
 inline float f_down(double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; }
 inline float f_up(double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; }
@@ -59,6 +50,7 @@ struct Compiler {
     CompiledScene& out;
     std::map<std::pair<long long, std::pair<long long, std::pair<long long, long long>>>, uint32_t> xform_cache;
     double pad_scale = 0.0;   // largest |coordinate| of the world's bounding box
+    std::map<std::vector<long long>, uint32_t> wrap_cache;
 
     Compiler(const RtSceneDesc& desc, CompiledScene& o) : d(desc), out(o) {}
 
@@ -146,11 +138,30 @@ struct Compiler {
     }
     static void apply_rotate(Chain& c, double degrees) { c.theta += degrees * PI / 180.0; c.identity = false; }
 
+    uint32_t intern_wrap(const Chain& c) {
+        if (c.ops.empty()) return 0;
+        if (c.ops.size() > rtd::MAX_WRAP_OPS) { out.error = "a chain of more than 6 Translate/RotateY/FlipFace wrappers must be restructured"; return 0; }
+        std::vector<long long> key{(long long)c.xform_id};
+        for (const auto& o : c.ops) { key.push_back(o.kind); key.push_back((long long)std::llround(o.degrees * 1048576.0)); }
+        auto it = wrap_cache.find(key);
+        if (it != wrap_cache.end()) return it->second;
+        rtd::Wrap w{};
+        w.xform = c.xform_id; w.n_ops = (uint32_t)c.ops.size();
+        for (size_t i = 0; i < c.ops.size(); ++i) {
+            const double radians = c.ops[i].degrees * PI / 180.0;   // rt_weekend.rs:4-6
+            w.op[i].kind = c.ops[i].kind; w.op[i].sin_t = (float)std::sin(radians); w.op[i].cos_t = (float)std::cos(radians);
+        }
+        out.wraps.push_back(w);
+        if (out.wraps.size() > rtd::MAX_WRAPS) fail("more than 1024 distinct wrapper chains");
+        wrap_cache[key] = (uint32_t)out.wraps.size() - 1;
+        return (uint32_t)out.wraps.size() - 1;
+    }
+
     // ---- primitives ----
     uint32_t meta_for(const RtHittable& h, const Chain& c) {
         if (h.material < 0 || (uint64_t)h.material >= d.n_materials) { fail("primitive without a valid material"); return 0; }
         if ((uint32_t)h.material > rtd::META_MAT_MASK) { fail("too many materials"); return 0; }
-        return rtd::make_meta((uint32_t)h.material, fold_ff_mode(c.ops), c.xform_id);
+        return rtd::make_meta((uint32_t)h.material, intern_wrap(c));
     }
     void push_leaf_node(uint32_t type, uint32_t first, uint32_t count) {
         if (first > rtd::LEAF_MAX_FIRST) { fail("too many primitives of one type"); return; }
@@ -185,9 +196,9 @@ struct Compiler {
         while (true) {
             const RtHittable* h = H(id); if (!h) return -1;
             if (++depth > 128) { fail("wrapper chain too deep"); return -1; }
-            if (h->kind == RT_HIT_TRANSLATE) { apply_translate(c, h->p); c.ops.push_back('W'); id = h->first_child; }
-            else if (h->kind == RT_HIT_ROTATE_Y) { apply_rotate(c, h->p[0]); c.ops.push_back('W'); id = h->first_child; }
-            else if (h->kind == RT_HIT_FLIP_FACE) { c.ops.push_back('F'); id = h->first_child; }
+            if (h->kind == RT_HIT_TRANSLATE) { apply_translate(c, h->p); c.ops.push_back({rtd::WO_TRANSLATE, 0.0}); id = h->first_child; }
+            else if (h->kind == RT_HIT_ROTATE_Y) { apply_rotate(c, h->p[0]); c.ops.push_back({rtd::WO_ROTATE_Y, h->p[0]}); id = h->first_child; }
+            else if (h->kind == RT_HIT_FLIP_FACE) { c.ops.push_back({rtd::WO_FLIP_FACE, 0.0}); id = h->first_child; }
             else return id;
         }
     }
@@ -485,6 +496,7 @@ int compile_scene(const RtSceneDesc& desc, CompiledScene& out) {
         (desc.n_perlins && !desc.perlins) || (desc.n_images && !desc.images)) { out.error = "null array with non-zero count"; return RT_ERR_INVALID; }
     Compiler c(desc, out);
     out.xforms.push_back(rtd::Xform{0.f, 1.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
+    out.wraps.push_back(rtd::Wrap{});
     c.compile_materials();
     if (!c.ok()) return RT_ERR_INVALID;
     {
@@ -496,6 +508,7 @@ int compile_scene(const RtSceneDesc& desc, CompiledScene& out) {
     Chain root;
     c.emit(desc.world, root);
     if (!c.ok()) return out.error.find("must be") != std::string::npos ? RT_ERR_UNSUPPORTED : RT_ERR_INVALID;
+    if (out.xforms.size() > 255) { out.error = "more than 255 distinct instance transforms must be flattened by the caller"; return RT_ERR_UNSUPPORTED; }
     c.merge_runs();
     c.fold_box_leaf();
     c.compile_lights();

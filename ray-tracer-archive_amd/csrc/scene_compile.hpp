@@ -16,6 +16,7 @@ struct CompiledScene {
     std::vector<rtd::Float4> tris;     std::vector<uint32_t> tri_meta;       // 3 per primitive
     std::vector<rtd::Medium> media;
     std::vector<rtd::Xform> xforms;                                          // [0] = identity
+    std::vector<rtd::Wrap> wraps;                                            // [0] = no wrappers
     std::vector<rtd::Float4> mat_a;    std::vector<uint32_t> mat_b;
     std::vector<rtd::Texture> textures;
     std::vector<rtd::PerlinTable> perlins;

@@ -152,3 +152,24 @@ def test_big_scene_compiles_fast(pkg):
     assert info["n_spheres"] == 200000 and info["n_tris"] == 2 * 64 * 32 and info["n_rects"] == 1
     assert info["fits_lds"] == 0
     assert dt < 60
+
+
+def test_wrap_records(pkg):
+    """Every distinct Translate/RotateY/FlipFace chain above a primitive becomes one wrap; a chain that moves
+    the ray becomes one ENTER/EXIT pair around the child's nodes."""
+    b = pkg.SceneBuilder()
+    m = b.lambertian((1, 1, 1))
+    box = b.box((0, 0, 0), (1, 1, 1), m)
+    world = b.hittable_list([b.translate(b.rotate_y(box, 15), (1, 2, 3)), b.flip_face(b.xz_rect(0, 1, 0, 1, 5, m)), b.sphere((0, 0, 0), 1, m)])
+    nodes, _, _ = pkg.compile_dump(b.desc(world))
+    kinds = [int(n["leaf"]) >> 28 for n in nodes]
+    assert kinds == [6, 3, 7, 3, 1]                       # ENTER, 6 rects, EXIT, flipped rect, sphere
+    info = pkg.compile_info(b.desc(world))
+    assert info["n_xforms"] == 2 and info["n_rects"] == 7
+    b2 = pkg.SceneBuilder()
+    m2 = b2.lambertian((1, 1, 1))
+    s = b2.sphere((0, 0, 0), 1, m2)
+    for _ in range(7):
+        s = b2.translate(s, (1, 0, 0))
+    with pytest.raises(pkg.RtError):
+        pkg.compile_info(b2.desc(b2.hittable_list([s])))       # more than 6 wrappers in one chain
