@@ -71,10 +71,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal on a one-GPU box: RT_BENCH_REHEARSAL=1 puts every rank on cuda:0 and gathers with gloo
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     n_gpus = max(world, 1)
     if args.gpus != n_gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
@@ -97,6 +104,12 @@ def main():
         stats_acc.append(ctx.render_device(scene, cam, prm, out.data_ptr()))
 
     def step():
+        if rehearsal and dist is not None:      # gloo cannot gather device tensors: stage through the host
+            def shard_to_host(prm, out):
+                t = torch.zeros(out.numel(), dtype=torch.float32, device=dev)
+                render_shard(prm, t)
+                out.copy_(t.cpu())
+            return D.render_sharded(shard_to_host, base, rank, n_gpus, dist, device="cpu")
         return D.render_sharded(render_shard, base, rank, n_gpus, dist, device=dev)
 
     for _ in range(args.warmup):
@@ -112,8 +125,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    cdev = "cpu" if rehearsal else dev
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -124,7 +138,7 @@ def main():
     launches = sum(s["extend_launches"] for s in stats_acc)
     samples_rank = sum(s["samples"] for s in stats_acc)
     if dist is not None:
-        t = torch.tensor([samples_rank], dtype=torch.float64, device=dev)
+        t = torch.tensor([samples_rank], dtype=torch.float64, device=cdev)
         dist.all_reduce(t)
         samples_total = float(t.item())
     else:

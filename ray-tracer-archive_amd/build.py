@@ -11,7 +11,10 @@ HEADERS = ["csrc/kernels.h", "csrc/device_types.h", "csrc/scene_compile.hpp", "h
 # -ffp-contract=off: a float expression means the same IEEE operations wherever it is inlined, so a
 # sample's radiance does not depend on which kernel / call site generated its camera ray (and the
 # device evaluates the reference's expressions in the order written). Hot loops spell out fmaf/fma.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-ffp-contract=off",
+         # every atomic here is already one-per-wave / one-per-workgroup; LLVM's wave-aggregation pass would only add a
+         # readfirstlane that forces an immediate wait on the returning atomic (k_extend grabs its chunk one ahead)
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def needs_build():

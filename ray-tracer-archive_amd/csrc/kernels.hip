@@ -323,6 +323,8 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
     const uint32_t count = *count_ptr;
     uint32_t w_next = 0, w_end = 0;
     bool exhausted = false;
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    uint32_t chunk = count > kChunk * n_waves ? kChunk : max(64u, (count / (2u * n_waves)) & ~63u);
 
     bool have = false;
     uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE, pend = 0, from = 0;
@@ -345,11 +347,17 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
         if (!exhausted && ((int)__popcll(idle) >= kRefillMin || (idle != 0ull && __ballot(have) == 0ull))) {
             uint32_t avail = w_end - w_next;
             if (avail == 0u) {
+                // guided self-scheduling: full chunks while the queue is long, smaller ones near its end so
+                // that the last waves to finish hold 64 rays, not 256 (one atomic per chunk either way)
                 uint32_t start = 0;
-                if ((threadIdx.x & 63u) == 0u) start = atomicAdd(head, kChunk);
+                if ((threadIdx.x & 63u) == 0u) start = atomicAdd(head, chunk);
                 start = first_lane_u32(start);
                 if (start >= count) exhausted = true;
-                else { w_next = start; w_end = min(start + kChunk, count); avail = w_end - w_next; }
+                else {
+                    w_next = start; w_end = min(start + chunk, count); avail = w_end - w_next;
+                    const uint32_t left = count - w_end;
+                    chunk = left > kChunk * n_waves ? kChunk : max(64u, (left / (2u * n_waves)) & ~63u);
+                }
             }
             if (avail != 0u) {
                 const uint32_t rank = lane_rank(idle);

@@ -54,7 +54,7 @@ struct RtScene {
     rtk::SceneDev dev{};
     uint32_t features = 0; bool in_lds = false;
     int bg_mode = 0; float bg[3] = {0, 0, 0};
-    uint64_t n_nodes = 0, n_prims = 0, bytes = 0;
+    uint64_t n_nodes = 0, n_prims = 0, bytes = 0, lds_bytes = 0;
 };
 
 namespace {
@@ -173,7 +173,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     const uint32_t f = scene_features(cs);
     s->features = f;
     const size_t lds_bytes = cs.nodes.size() * 32 + cs.spheres.size() * 16;
-    s->in_lds = lds_bytes <= kLdsSceneBudget;
+    s->in_lds = lds_bytes <= kLdsSceneBudget; s->lds_bytes = lds_bytes;
     s->bg_mode = cs.background_mode; for (int i = 0; i < 3; ++i) s->bg[i] = cs.background[i];
     s->n_nodes = cs.nodes.size();
     s->n_prims = cs.sphere_meta.size() + cs.moving_meta.size() + cs.rect_meta.size() + cs.tri_meta.size() + cs.media.size();
@@ -271,7 +271,11 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
 
     const bool counting = (prm->flags & RT_FLAG_COUNTERS) != 0, timing = (prm->flags & RT_FLAG_TIMING) != 0;
     rtk::LaunchCfg cfg{};
-    cfg.extend_blocks = (uint32_t)ctx->n_cu * 8u; cfg.features = scene->features; cfg.scene_in_lds = scene->in_lds;
+    // persistent grid = what is resident at once: 8 workgroups of 256 per CU by registers, fewer when the
+    // LDS copy of the scene (nodes + sphere records) limits it
+    uint32_t per_cu = 8u;
+    if (scene->in_lds) per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (uint32_t)((160u * 1024u) / std::max<uint64_t>(1024u, scene->lds_bytes))));
+    cfg.extend_blocks = (uint32_t)ctx->n_cu * per_cu; cfg.features = scene->features; cfg.scene_in_lds = scene->in_lds;
 
     size_t ev_used = 0;
     auto next_event = [&](hipEvent_t& ev) -> hipError_t {
