@@ -135,6 +135,12 @@ typedef enum RtBackgroundMode {
                                not in the reference (it only has the constant colour) */
 } RtBackgroundMode;
 
+typedef enum RtBvhBuilder {
+    RT_BVH_REFERENCE = 0,  /* BVHNode::construct as intended (bvh.rs:77-130): random axis, median split */
+    RT_BVH_SAH = 1         /* binned surface-area heuristic: same pictures (a BVH only culls), far fewer
+                              node visits on large scenes; SURVEY.md 8(f) rank 1 */
+} RtBvhBuilder;
+
 typedef struct RtSceneDesc {
     uint32_t abi_version;   /* RT_ABI_VERSION */
     uint32_t _pad0;
@@ -148,7 +154,7 @@ typedef struct RtSceneDesc {
     int32_t lights;           /* root of the lights list (main.rs:669-686) or -1: no lights, the
                                  integrator then samples CosinePdf only (book-1/2 behaviour) */
     int32_t background_mode;  /* RtBackgroundMode */
-    int32_t _pad1;
+    int32_t bvh_builder;      /* RtBvhBuilder: how RT_HIT_BVH objects are built on the device side */
     RtVec3 background;        /* constant colour, or the sky gradient's far colour (0.5,0.7,1.0) */
     uint64_t bvh_seed;        /* seeds the per-node axis draw of BVHNode::construct (bvh.rs:87) */
 } RtSceneDesc;

@@ -20,7 +20,8 @@ typedef struct RtHostScene RtHostScene;   /* owns the storage behind an RtSceneD
  *       "book1_ref" (the reference's remnant: checker ground + MovingSpheres, main.rs:180-218),
  *       "cornell" (main.rs:337-433 + lights main.rs:669-684), "cornell_smoke" (main.rs:435-519),
  *       "final" (main.rs:521-649; `image` = decoded earthmap RGB8 or NULL),
- *       "big" (BASELINE config 5: arg0 spheres + a torus mesh of subdivision arg1).
+ *       "big" (BASELINE config 5: arg0 spheres + a torus mesh of subdivision arg1);
+ *       a "_sah" suffix ("big_sah", "book1_sah") selects RT_BVH_SAH for the scene's BVH objects.
  * scene_seed seeds the scene's random draws; desc.bvh_seed is derived from it. */
 int rt_host_scene_create(const char* name, uint64_t scene_seed, uint64_t arg0, uint64_t arg1,
                          const uint8_t* image, uint32_t image_w, uint32_t image_h, RtHostScene** out);

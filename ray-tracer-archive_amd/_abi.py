@@ -11,6 +11,7 @@ RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT, RT_MAT
 (RT_HIT_SPHERE, RT_HIT_MOVING_SPHERE, RT_HIT_XY_RECT, RT_HIT_XZ_RECT, RT_HIT_YZ_RECT, RT_HIT_TRIANGLE, RT_HIT_BOX, RT_HIT_LIST,
  RT_HIT_BVH, RT_HIT_TRANSLATE, RT_HIT_ROTATE_Y, RT_HIT_FLIP_FACE, RT_HIT_CONSTANT_MEDIUM) = range(13)
 RT_BG_CONSTANT, RT_BG_SKY_GRADIENT = 0, 1
+RT_BVH_REFERENCE, RT_BVH_SAH = 0, 1
 RT_NAN_PER_SAMPLE, RT_NAN_REFERENCE = 0, 1
 RT_FLAG_COUNTERS, RT_FLAG_TIMING = 1, 2
 
@@ -55,7 +56,7 @@ class RtSceneDesc(C.Structure):
                 ("textures", C.POINTER(RtTexture)), ("n_textures", C.c_uint64),
                 ("perlins", C.POINTER(RtPerlin)), ("n_perlins", C.c_uint64),
                 ("images", C.POINTER(RtImage)), ("n_images", C.c_uint64),
-                ("world", C.c_int32), ("lights", C.c_int32), ("background_mode", C.c_int32), ("_pad1", C.c_int32),
+                ("world", C.c_int32), ("lights", C.c_int32), ("background_mode", C.c_int32), ("bvh_builder", C.c_int32),
                 ("background", RtVec3), ("bvh_seed", C.c_uint64)]
 
 

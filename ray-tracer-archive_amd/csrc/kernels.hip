@@ -1025,15 +1025,31 @@ static hipError_t launch_extend_t(const LaunchCfg& cfg, const SceneDev& sc, cons
     return hipGetLastError();
 }
 
+// Kernel variants are compiled for a few feature sets; a scene runs on the smallest one that covers it.
+//   0                    static spheres, Lambertian/Metal/Dielectric (book 1)
+//   F_RECT | F_TRI       + rects and triangles, no wrappers/media/textures/lights (BASELINE config 5)
+//   F_ALL                everything
+constexpr uint32_t kVariantMesh = F_RECT | F_TRI;
+static uint32_t pick_variant(uint32_t need) {
+    if (need == 0u) return 0u;
+    if ((need & ~kVariantMesh) == 0u) return kVariantMesh;
+    return F_ALL;
+}
+
 hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                          uint32_t* head, uint32_t* cz, unsigned long long* counters, bool count, hipStream_t stream) {
-    const bool simple = (cfg.features == 0u);
-    if (cfg.scene_in_lds) {
-        if (simple) return launch_extend_t<true, 0u>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream);
-        return launch_extend_t<true, F_ALL>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream);
-    }
-    if (simple) return launch_extend_t<false, 0u>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream);
-    return launch_extend_t<false, F_ALL>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream);
+    const uint32_t v = pick_variant(cfg.features);
+#define RT_EXT(LDSV, F) launch_extend_t<LDSV, F>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream)
+    if (cfg.scene_in_lds) return v == 0u ? RT_EXT(true, 0u) : (v == kVariantMesh ? RT_EXT(true, kVariantMesh) : RT_EXT(true, F_ALL));
+    return v == 0u ? RT_EXT(false, 0u) : (v == kVariantMesh ? RT_EXT(false, kVariantMesh) : RT_EXT(false, F_ALL));
+#undef RT_EXT
+}
+
+template <uint32_t FEAT>
+static void launch_shade_t(uint32_t blocks, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, const uint32_t* count_in,
+                           uint32_t* count_out, uint32_t* next_work, uint32_t* hz, unsigned long long* counters, bool count, hipStream_t stream) {
+    if (count) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
+    else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
 }
 
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
@@ -1041,14 +1057,10 @@ hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev&
                         hipStream_t stream) {
     const uint32_t blocks = (max_count + kShadeThreads - 1u) / kShadeThreads;
     if (blocks == 0u) return hipSuccess;
-    const bool simple = (cfg.features == 0u);
-    if (simple) {
-        if (count) hipLaunchKernelGGL((k_shade<0u, true>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
-        else hipLaunchKernelGGL((k_shade<0u, false>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
-    } else {
-        if (count) hipLaunchKernelGGL((k_shade<F_ALL, true>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
-        else hipLaunchKernelGGL((k_shade<F_ALL, false>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
-    }
+    const uint32_t v = pick_variant(cfg.features);
+    if (v == 0u) launch_shade_t<0u>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);
+    else if (v == kVariantMesh) launch_shade_t<kVariantMesh>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);
+    else launch_shade_t<F_ALL>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);
     return hipGetLastError();
 }
 

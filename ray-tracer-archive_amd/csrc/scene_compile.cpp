@@ -303,7 +303,86 @@ struct Compiler {
         }
         std::vector<int> order(n); for (int i = 0; i < n; ++i) order[i] = i;
         B.axis_state = fin(d.bvh_seed + GAMMA * (uint64_t)(id + 1));
-        build_range(B, order, 0, (size_t)n, ctx, depth);
+        if (d.bvh_builder == RT_BVH_SAH) build_sah(B, order, 0, (size_t)n, ctx, depth);
+        else build_range(B, order, 0, (size_t)n, ctx, depth);
+    }
+
+    static double half_area(const Box3& b) {
+        const double dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    void finish_box_node(uint32_t me, const Box3& box) {
+        rtd::Node& n = out.nodes[me];
+        for (int i = 0; i < 3; ++i) {
+            n.mn[i] = f_down(box.mn[i] - 1e-6 * (std::fabs(box.mn[i]) + pad_scale));
+            n.mx[i] = f_up(box.mx[i] + 1e-6 * (std::fabs(box.mx[i]) + pad_scale));
+        }
+        n.leaf = 0;
+        n.skip = (uint32_t)out.nodes.size();
+    }
+
+    // RT_BVH_SAH: top-down binned surface-area heuristic (16 bins per axis). Not the reference's tree —
+    // an option for large scenes; the picture is the same because a BVH only culls. Children are laid out
+    // lower-coordinate first (the threaded walk has one fixed order for all rays).
+    Box3 build_sah(Build& B, std::vector<int>& order, size_t start, size_t end, const Chain& ctx, int depth) {
+        const size_t n = end - start;
+        const uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.push_back(rtd::Node{});
+        out.n_box_nodes++;
+        Box3 box = range_box(B, order, start, end);
+        auto make_leaf = [&]() { for (size_t i = start; i < end; ++i) emit(B.obj[order[i]], ctx, depth + 1); finish_box_node(me, box); return box; };
+        if (n <= 2 || depth > 100) return make_leaf();
+        constexpr int NB = 16;
+        double cmn[3], cmx[3];
+        for (int a = 0; a < 3; ++a) { cmn[a] = std::numeric_limits<double>::infinity(); cmx[a] = -cmn[a]; }
+        for (size_t i = start; i < end; ++i) {
+            const Box3& b = B.box[order[i]];
+            for (int a = 0; a < 3; ++a) { const double c = 0.5 * (b.mn[a] + b.mx[a]); cmn[a] = std::min(cmn[a], c); cmx[a] = std::max(cmx[a], c); }
+        }
+        double best_cost = std::numeric_limits<double>::infinity(); int best_axis = -1, best_split = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double ext = cmx[a] - cmn[a];
+            if (!(ext > 0)) continue;
+            size_t cnt[NB] = {0}; Box3 bb[NB]; bool used[NB] = {false};
+            const double scale = NB / ext;
+            for (size_t i = start; i < end; ++i) {
+                const Box3& b = B.box[order[i]];
+                int k = (int)((0.5 * (b.mn[a] + b.mx[a]) - cmn[a]) * scale); if (k >= NB) k = NB - 1; if (k < 0) k = 0;
+                bb[k] = used[k] ? surrounding(bb[k], b) : b; used[k] = true; cnt[k]++;
+            }
+            double right_area[NB]; size_t right_cnt[NB]; Box3 acc{}; bool have_acc = false; size_t c = 0;
+            for (int k = NB - 1; k >= 1; --k) {
+                if (used[k]) { acc = have_acc ? surrounding(acc, bb[k]) : bb[k]; have_acc = true; }
+                c += cnt[k]; right_cnt[k] = c; right_area[k] = have_acc ? half_area(acc) : 0.0;
+            }
+            have_acc = false; c = 0;
+            for (int k = 0; k < NB - 1; ++k) {
+                if (used[k]) { acc = have_acc ? surrounding(acc, bb[k]) : bb[k]; have_acc = true; }
+                c += cnt[k];
+                if (c == 0 || right_cnt[k + 1] == 0) continue;
+                const double cost = half_area(acc) * (double)c + right_area[k + 1] * (double)right_cnt[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k + 1; }
+            }
+        }
+        const double leaf_cost = half_area(box) * (double)n * 1.5;
+        if (best_axis < 0 || (n <= 6 && 1.0 * half_area(box) + 1.5 * best_cost >= leaf_cost)) {
+            if (n <= rtd::LEAF_MAX_COUNT) return make_leaf();
+            // many coincident centroids: fall back to an index median
+            const size_t mid = start + n / 2;
+            const Box3 bl = build_sah(B, order, start, mid, ctx, depth + 1), br = build_sah(B, order, mid, end, ctx, depth + 1);
+            (void)bl; (void)br;
+            finish_box_node(me, box);
+            return box;
+        }
+        const double ext = cmx[best_axis] - cmn[best_axis], scale = NB / ext;
+        auto bin_of = [&](int idx) { const Box3& b = B.box[idx]; int k = (int)((0.5 * (b.mn[best_axis] + b.mx[best_axis]) - cmn[best_axis]) * scale); return k >= NB ? NB - 1 : (k < 0 ? 0 : k); };
+        auto midit = std::stable_partition(order.begin() + start, order.begin() + end, [&](int idx) { return bin_of(idx) < best_split; });
+        size_t mid = (size_t)(midit - order.begin());
+        if (mid == start || mid == end) mid = start + n / 2;
+        build_sah(B, order, start, mid, ctx, depth + 1);
+        build_sah(B, order, mid, end, ctx, depth + 1);
+        finish_box_node(me, box);
+        return box;
     }
 
     Box3 range_box(const Build& B, const std::vector<int>& order, size_t s, size_t e) {
@@ -339,19 +418,13 @@ struct Compiler {
             const Box3 br = build_range(B, order, mid, end, ctx, depth + 1);
             box = surrounding(bl, br);
         }
-        rtd::Node& n = out.nodes[me];
         // boxes live in the space the children are traversed in; children under an instance
         // transform are traversed in local space, where the reference's boxes are defined too.
         // The device slab test evaluates fma(bound, 1/d, -o/d) with a 1-ulp reciprocal: its absolute
         // error is a few 1e-7 * (|bound| + |o|) / |d|, so each bound moves outwards by that much with
         // |o| <= scene extent (pad_scale, set by compile_scene). A BVH only culls: a looser box
         // costs visits, never a hit.
-        for (int i = 0; i < 3; ++i) {
-            n.mn[i] = f_down(box.mn[i] - 1e-6 * (std::fabs(box.mn[i]) + pad_scale));
-            n.mx[i] = f_up(box.mx[i] + 1e-6 * (std::fabs(box.mx[i]) + pad_scale));
-        }
-        n.leaf = 0;
-        n.skip = (uint32_t)out.nodes.size();
+        finish_box_node(me, box);
         return box;
     }
 

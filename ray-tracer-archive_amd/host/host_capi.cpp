@@ -28,9 +28,12 @@ int rt_host_scene_create(const char* name, uint64_t scene_seed, uint64_t arg0, u
     else if (n == "cornell") s->recipe = rt::cornell_box();
     else if (n == "cornell_smoke") s->recipe = rt::cornell_smoke();
     else if (n == "final") s->recipe = rt::final_scene(scene_seed, image, image_w, image_h);
-    else if (n == "big") s->recipe = rt::big_scene(scene_seed, (uint32_t)arg0, (uint32_t)arg1);
+    else if (n == "big" || n == "big_sah") s->recipe = rt::big_scene(scene_seed, (uint32_t)arg0, (uint32_t)arg1);
+    else if (n == "book1_sah") s->recipe = rt::random_scene(scene_seed, 0, true);
     else { delete s; return RT_ERR_INVALID; }
-    s->flat.finish(s->recipe.world, s->recipe.lights, s->recipe.background_mode, s->recipe.background, rt::SceneRng::fin(scene_seed ^ 0xB5AD4ECEDA1CE2A9ull));
+    const bool sah = n.size() > 4 && n.compare(n.size() - 4, 4, "_sah") == 0;
+    s->flat.finish(s->recipe.world, s->recipe.lights, s->recipe.background_mode, s->recipe.background, rt::SceneRng::fin(scene_seed ^ 0xB5AD4ECEDA1CE2A9ull),
+                   sah ? RT_BVH_SAH : RT_BVH_REFERENCE);
     *out = s;
     return RT_OK;
 }

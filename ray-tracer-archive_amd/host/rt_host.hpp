@@ -231,7 +231,8 @@ struct FlatScene {
         hittables.push_back(r); hid[h.get()] = (int32_t)hittables.size() - 1;
         return (int32_t)hittables.size() - 1;
     }
-    void finish(const HittablePtr& world, const HittablePtr& lights, int background_mode, const Color3& background, uint64_t bvh_seed) {
+    void finish(const HittablePtr& world, const HittablePtr& lights, int background_mode, const Color3& background, uint64_t bvh_seed,
+                int bvh_builder = RT_BVH_REFERENCE) {
         desc.abi_version = RT_ABI_VERSION;
         desc.world = add_hittable(world);
         desc.lights = lights ? add_hittable(lights) : -1;
@@ -241,7 +242,7 @@ struct FlatScene {
         desc.textures = textures.data(); desc.n_textures = textures.size();
         desc.perlins = perlins.data(); desc.n_perlins = perlins.size();
         desc.images = images.data(); desc.n_images = images.size();
-        desc.background_mode = background_mode; desc.background = background.abi(); desc.bvh_seed = bvh_seed;
+        desc.background_mode = background_mode; desc.background = background.abi(); desc.bvh_seed = bvh_seed; desc.bvh_builder = bvh_builder;
     }
 };
 

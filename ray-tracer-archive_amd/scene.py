@@ -10,10 +10,10 @@ from . import _abi as A
 
 
 class SceneBuilder:
-    def __init__(self, background=(0.0, 0.0, 0.0), background_mode=A.RT_BG_CONSTANT, bvh_seed=1):
+    def __init__(self, background=(0.0, 0.0, 0.0), background_mode=A.RT_BG_CONSTANT, bvh_seed=1, bvh_builder=A.RT_BVH_REFERENCE):
         self.hittables, self.children, self.materials, self.textures, self.perlins, self.images = [], [], [], [], [], []
         self._image_arrays = []
-        self.background, self.background_mode, self.bvh_seed = background, background_mode, bvh_seed
+        self.background, self.background_mode, self.bvh_seed, self.bvh_builder = background, background_mode, bvh_seed, bvh_builder
         self._keep = None
 
     # ---- textures (texture.rs) ----
@@ -144,5 +144,6 @@ class SceneBuilder:
         d.background_mode = self.background_mode
         d.background = A.RtVec3(*map(float, self.background))
         d.bvh_seed = self.bvh_seed
+        d.bvh_builder = self.bvh_builder
         self._keep = keep   # the desc points into these arrays
         return d
