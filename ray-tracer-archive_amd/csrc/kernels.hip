@@ -313,18 +313,34 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
     const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
     const float4* spheres = reinterpret_cast<const float4*>(sc.spheres);
     if (LDS) {
-        // stage the node records and the sphere records (the whole BVH for book-1-sized scenes)
-        const uint32_t n4 = 2 * n_nodes, s4 = sc.n_spheres;
-        for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) lds[i] = nodes[i];
-        for (uint32_t i = threadIdx.x; i < s4; i += blockDim.x) lds[n4 + i] = spheres[i];
+        // stage the node records and the sphere records (the whole BVH for book-1-sized scenes): a linear
+        // copy, i.e. exactly the shape of LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, LDS
+        // address = wave base + lane * 16, no VGPR round trip); all pieces in flight, then one wait + barrier
+        const uint32_t n4 = 2 * n_nodes, s4 = sc.n_spheres, tot = n4 + s4;      // nodes then spheres, contiguous in LDS
+        const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63u, nw = blockDim.x >> 6;
+        for (uint32_t base = wave * 64u; base < tot; base += nw * 64u) {
+            const uint32_t i = base + ln;
+            if (i < tot) {
+                const float4* src = i < n4 ? nodes + i : spheres + (i - n4);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lds + base), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         nodes = lds; spheres = lds + n4;
     }
     const uint32_t count = *count_ptr;
-    uint32_t w_next = 0, w_end = 0;
-    bool exhausted = false;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     uint32_t chunk = count > kChunk * n_waves ? kChunk : max(64u, (count / (2u * n_waves)) & ~63u);
+    // the first chunk of every wave is static (wave w owns [w*chunk, (w+1)*chunk)); the queue head counts from
+    // behind them. Otherwise every wave of the grid would hit the head with a returning atomic in the same
+    // microsecond (same-address atomics serialise, ~11 ns each).
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t w_next = min(wave_id * chunk, count), w_end = min(w_next + chunk, count);
+    bool exhausted = false;
+    const uint32_t head0 = n_waves * chunk;         // the dynamic part of the queue starts behind the static chunks
 
     bool have = false;
     uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE, pend = 0, from = 0;
@@ -340,32 +356,27 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
 #else
 #define STAMP(x)
 #endif
+    // One outer iteration = one refill. The ray records of the next 64 queue slots are loaded into No/Nd at
+    // the END of a refill (one unconditional definition per iteration, so hipcc keeps the loads in flight) and
+    // handed out at the NEXT refill by __shfl (ds_bpermute): the wave no longer parks on HBM latency with
+    // its other lanes' rays stalled. Only the chunk atomic (once per 256 rays) is still waited for in place.
+    Float4 No = Float4{0, 0, 0, 0}, Nd = Float4{0, 0, 1, 0};
+    uint32_t n_cnt = 0;                // valid prefetched entries: slots [w_next, w_next + n_cnt)
     for (;;) {
         STAMP(st_a);
-        // ---- refill: idle lanes take the next rays of this wave's chunk (ballot + prefix rank) ----
-        const uint64_t idle = __ballot(!have);
-        if (!exhausted && ((int)__popcll(idle) >= kRefillMin || (idle != 0ull && __ballot(have) == 0ull))) {
-            uint32_t avail = w_end - w_next;
-            if (avail == 0u) {
-                // guided self-scheduling: full chunks while the queue is long, smaller ones near its end so
-                // that the last waves to finish hold 64 rays, not 256 (one atomic per chunk either way)
-                uint32_t start = 0;
-                if ((threadIdx.x & 63u) == 0u) start = atomicAdd(head, chunk);
-                start = first_lane_u32(start);
-                if (start >= count) exhausted = true;
-                else {
-                    w_next = start; w_end = min(start + chunk, count); avail = w_end - w_next;
-                    const uint32_t left = count - w_end;
-                    chunk = left > kChunk * n_waves ? kChunk : max(64u, (left / (2u * n_waves)) & ~63u);
-                }
-            }
-            if (avail != 0u) {
+        // ---- refill: idle lanes take prefetched rays (ballot + prefix rank) ----
+        {
+            const uint64_t idle = __ballot(!have);
+            const uint32_t take = min((uint32_t)__popcll(idle), n_cnt);
+            if (take != 0u) {
                 const uint32_t rank = lane_rank(idle);
-                if (!have && rank < avail) {
+                const int src = (int)(rank & 63u);
+                const float ox = __shfl(No.x, src), oy = __shfl(No.y, src), oz = __shfl(No.z, src), ot = __shfl(No.w, src);
+                const float dx = __shfl(Nd.x, src), dy = __shfl(Nd.y, src), dz = __shfl(Nd.z, src), dfrom = __shfl(Nd.w, src);
+                if (!have && rank < take) {
                     slot = w_next + rank;
-                    const Float4 ro = pool.ray_o[slot], rdv = pool.ray_d[slot];
-                    o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
-                    from = __float_as_uint(rdv.w);            // primitive this ray starts on (0: camera / medium)
+                    o = v3(ox, oy, oz); d = v3(dx, dy, dz); tm = ot;
+                    from = __float_as_uint(dfrom);            // primitive this ray starts on (0: camera / medium)
                     inv = v3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));   // culling only: boxes carry the slack (scene_compile.cpp)
                     oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
                     a = len2(d);
@@ -378,16 +389,35 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
                     }
                     tmax = kInf; node = 0; hit_prim = rtd::HIT_NONE; pend = 0; have = true;
                 }
-                const uint32_t n_idle = (uint32_t)__popcll(idle);
-                w_next += min(n_idle, avail);
+                w_next += take;
             }
+            if (!exhausted && w_next == w_end) {
+                // guided self-scheduling: full chunks while the queue is long, smaller ones near its end so
+                // that the last waves to finish hold 64 rays, not 256 (one atomic per chunk either way)
+                uint32_t start = 0;
+                if (lane == 0u) start = atomicAdd(head, chunk);
+                start = first_lane_u32(start) + head0;
+                if (start >= count) exhausted = true;
+                else {
+                    w_next = start; w_end = min(start + chunk, count);
+                    const uint32_t left = count - w_end;
+                    chunk = left > kChunk * n_waves ? kChunk : max(64u, (left / (2u * n_waves)) & ~63u);
+                }
+            }
+            // prefetch for the next refill: every lane loads (index clamped, slot 0 when nothing is left)
+            n_cnt = exhausted ? 0u : min(64u, w_end - w_next);
+            const uint32_t idx = n_cnt != 0u ? w_next + min(lane, n_cnt - 1u) : 0u;
+            No = pool.ray_o[idx]; Nd = pool.ray_d[idx];
         }
-        if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
+        if (__ballot(have) == 0ull && n_cnt == 0u) break;       // queue empty, nothing in flight
 #ifdef RT_STAMPS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         STAMP(st_b); st_refill += st_b - st_a;
 #endif
-
+        // ---- work until the next refill is due ----
+        for (;;) {
+#ifdef RT_STAMPS
+        STAMP(st_b);
+#endif
         // ---- node pass: branch-free steps. A lane that is not walking (no ray, holding a leaf, or past the
         // last node) re-reads node 0 and keeps its state; everything is a select, so a step is ~30 VALU, two
         // ds_read_b128 and no exec-mask traffic. ----
@@ -427,14 +457,13 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
             }
         }
 #ifdef RT_STAMPS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         STAMP(st_a); st_node += st_a - st_b;
 #endif
         // ---- primitive pass: when enough lanes hold a leaf, or nobody can walk any further ----
         const uint64_t pm = __ballot(pend != 0u);
-        if (pm == 0ull) continue;
-        if ((int)__popcll(pm) < kLeafBatch && __ballot(have && pend == 0u) != 0ull) continue;
-        if (pend != 0u) {
+        const bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(have && pend == 0u) == 0ull);
+        if (do_prims && pend != 0u) {
             const uint32_t type = pend >> 28, cnt = (pend >> 24) & 15u, first = pend & rtd::LEAF_MAX_FIRST;
             pend = 0u;
             if (type == rtd::LT_SPHERE) {
@@ -485,9 +514,14 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
             }
         }
 #ifdef RT_STAMPS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        STAMP(st_b); st_prim += st_b - st_a;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        { unsigned long long st_c; STAMP(st_c); st_prim += st_c - st_a; }
 #endif
+        // next refill is due when enough lanes are idle and there is something to hand out, or nobody has a ray
+        const uint64_t hv = __ballot(have);
+        if (hv == 0ull) break;
+        if (n_cnt != 0u && 64 - (int)__popcll(hv) >= kRefillMin) break;
+        }
     }
 #ifdef RT_STAMPS
     if ((threadIdx.x & 63u) == 0u) {
@@ -1047,7 +1081,8 @@ hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev
 
 template <uint32_t FEAT>
 static void launch_shade_t(uint32_t blocks, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, const uint32_t* count_in,
-                           uint32_t* count_out, uint32_t* next_work, uint32_t* hz, unsigned long long* counters, bool count, hipStream_t stream) {
+                           uint32_t* count_out, uint32_t* next_work, uint32_t* hz, unsigned long long* counters, bool count,
+                           hipStream_t stream) {
     if (count) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
     else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
 }

@@ -6,7 +6,7 @@ hs = p.HostScene('book1', 1)
 ctx = p.Context(0)
 scene = ctx.upload(hs.desc)
 cam = hs.camera(1.5)
-prm = p.make_params(1200, 800, 100, flags=2)
+prm = p.make_params(1200, 800, 500, flags=2)
 ctx.render(scene, cam, prm)
 img, st = ctx.render(scene, cam, prm)
 d = st['debug']
