@@ -85,6 +85,16 @@ struct Rng {
     DEVI float rnd() { return u01(next64()); }                               // rt_weekend.rs:8-11
     DEVI float range(float lo, float hi) { return lo + (hi - lo) * rnd(); }  // rt_weekend.rs:13-15
 };
+// sin/cos of 2*PI*x for x in [0,1): v_sin_f32 / v_cos_f32 take their argument in revolutions, so the
+// reference's `phi = 2*PI*r1; phi.cos()` (vec3.rs:258-260) is one hardware instruction each (abs. error
+// ~1e-6, far below the f32-vs-f64 differences already present); the libm path costs ~80 instructions.
+DEVI void sincos_2pi(float x, float& s, float& c) {
+#ifdef RT_LIBM_SINCOS
+    sincosf(2.0f * kPi * x, &s, &c);
+#else
+    s = __builtin_amdgcn_sinf(x); c = __builtin_amdgcn_cosf(x);
+#endif
+}
 DEVI V3 random_in_unit_sphere(Rng& g) {                                      // vec3.rs:78-86
     for (;;) {
         float a = g.range(-1.f, 1.f), b = g.range(-1.f, 1.f), c = g.range(-1.f, 1.f);
@@ -96,16 +106,14 @@ DEVI V3 random_in_unit_sphere(Rng& g) {                                      // 
 DEVI V3 random_cosine_direction(Rng& g) {                                    // vec3.rs:253-262
     float r1 = g.rnd(), r2 = g.rnd();
     float z = sqrtf(1.0f - r2);
-    float phi = 2.0f * kPi * r1;
-    float s, c; sincosf(phi, &s, &c);
+    float s, c; sincos_2pi(r1, s, c);                                       // phi = 2*PI*r1
     float sr = sqrtf(r2);
     return v3(c * sr, s * sr, z);
 }
 DEVI V3 random_to_sphere(Rng& g, float radius, float distance_sq) {          // pdf.rs:82-91
     float r1 = g.rnd(), r2 = g.rnd();
     float z = 1.0f + r2 * (sqrtf(1.0f - radius * radius / distance_sq) - 1.0f);
-    float phi = 2.0f * kPi * r1;
-    float s, c; sincosf(phi, &s, &c);
+    float s, c; sincos_2pi(r1, s, c);                                       // phi = 2*PI*r1
     float q = sqrtf(1.0f - z * z);
     return v3(c * q, s * q, z);
 }

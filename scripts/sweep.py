@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {
     "base": [],
+    "libm": ["RT_LIBM_SINCOS=1"],
     "stamps": ["RT_STAMPS=1"],
     "r1": ["RT_REFILL_MIN=1"],
     "r8": ["RT_REFILL_MIN=8"],
