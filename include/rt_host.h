@@ -21,6 +21,7 @@ typedef struct RtHostScene RtHostScene;   /* owns the storage behind an RtSceneD
  *       "cornell" (main.rs:337-433 + lights main.rs:669-684), "cornell_smoke" (main.rs:435-519),
  *       "final" (main.rs:521-649; `image` = decoded earthmap RGB8 or NULL),
  *       "big" (BASELINE config 5: arg0 spheres + a torus mesh of subdivision arg1);
+ *       "obj:<path>" (a Wavefront OBJ mesh, scaled by arg0 if non-zero, on a ground rect);
  *       a "_sah" suffix ("big_sah", "book1_sah") selects RT_BVH_SAH for the scene's BVH objects.
  * scene_seed seeds the scene's random draws; desc.bvh_seed is derived from it. */
 int rt_host_scene_create(const char* name, uint64_t scene_seed, uint64_t arg0, uint64_t arg1,

@@ -30,6 +30,17 @@ int rt_host_scene_create(const char* name, uint64_t scene_seed, uint64_t arg0, u
     else if (n == "final") s->recipe = rt::final_scene(scene_seed, image, image_w, image_h);
     else if (n == "big" || n == "big_sah") s->recipe = rt::big_scene(scene_seed, (uint32_t)arg0, (uint32_t)arg1);
     else if (n == "book1_sah") s->recipe = rt::random_scene(scene_seed, 0, true);
+    else if (n.rfind("obj:", 0) == 0) {
+        // "obj:<path>": the mesh alone on a ground rect (Lambertian 0.5), camera framing the unit-ish model
+        rt::HittableList world;
+        const long nt = rt::load_obj(n.substr(4), rt::Lambertian::construct(rt::Color3(0.7, 0.3, 0.3)), arg0 ? (double)arg0 : 1.0, rt::Vec3(0, 0, 0), world);
+        if (nt < 0) { delete s; return RT_ERR_INVALID; }
+        world.add(rt::XzRect::construct(-50, 50, -50, 50, -1.0, rt::Lambertian::construct(rt::Color3(0.5, 0.5, 0.5))));
+        s->recipe.world = rt::BVHNode::construct2(world, 0.0, 0.0);
+        s->recipe.background_mode = RT_BG_SKY_GRADIENT; s->recipe.background = rt::Color3(0.5, 0.7, 1.0);
+        s->recipe.lookfrom = rt::Point3(3, 2.5, 5); s->recipe.lookat = rt::Point3(0, 0, 0); s->recipe.vfov = 35; s->recipe.aperture = 0; s->recipe.focus_dist = 10;
+        s->recipe.time0 = 0; s->recipe.time1 = 0;
+    }
     else { delete s; return RT_ERR_INVALID; }
     const bool sah = n.size() > 4 && n.compare(n.size() - 4, 4, "_sah") == 0;
     s->flat.finish(s->recipe.world, s->recipe.lights, s->recipe.background_mode, s->recipe.background, rt::SceneRng::fin(scene_seed ^ 0xB5AD4ECEDA1CE2A9ull),

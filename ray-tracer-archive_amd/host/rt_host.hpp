@@ -12,6 +12,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -395,9 +397,48 @@ inline SceneRecipe final_scene(uint64_t scene_seed, const uint8_t* earth, uint32
     return r;
 }
 
+// Wavefront OBJ import (README.md:151-153 lists it as an optional task the reference never did; BASELINE
+// config 5 asks for an imported mesh). Supports `v x y z` and `f a b c ...` (1-based or negative indices,
+// `i/j/k` forms, polygons fanned into triangles). Vertices are mapped p -> p*scale + offset.
+// Returns the number of triangles added, or -1 if the file cannot be read.
+inline long load_obj(const std::string& path, std::shared_ptr<Material> m, double scale, const Vec3& offset, HittableList& into) {
+    FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) return -1;
+    std::vector<Point3> v;
+    long n_tri = 0;
+    char line[1024];
+    while (std::fgets(line, sizeof(line), f)) {
+        if (line[0] == 'v' && (line[1] == ' ' || line[1] == '\t')) {
+            double x, y, z;
+            if (std::sscanf(line + 2, "%lf %lf %lf", &x, &y, &z) == 3) v.push_back(Point3(x * scale, y * scale, z * scale) + offset);
+        } else if (line[0] == 'f' && (line[1] == ' ' || line[1] == '\t')) {
+            std::vector<long> idx;
+            char* p = line + 2;
+            while (*p) {
+                while (*p == ' ' || *p == '\t') ++p;
+                if (*p == 0 || *p == '\n' || *p == '\r') break;
+                char* end = nullptr;
+                long i = std::strtol(p, &end, 10);
+                if (end == p) break;
+                idx.push_back(i > 0 ? i - 1 : (long)v.size() + i);
+                p = end;
+                while (*p && *p != ' ' && *p != '\t' && *p != '\n') ++p;   // skip /vt/vn
+            }
+            for (size_t k = 2; k < idx.size(); ++k) {
+                const long a = idx[0], b = idx[k - 1], c = idx[k];
+                if (a < 0 || b < 0 || c < 0 || a >= (long)v.size() || b >= (long)v.size() || c >= (long)v.size()) continue;
+                into.add(Triangle::construct(v[a], v[b], v[c], m));
+                ++n_tri;
+            }
+        }
+    }
+    std::fclose(f);
+    return n_tri;
+}
+
 // BASELINE config 5: n random spheres resting on a flat ground + a procedurally generated triangle
 // mesh (no mesh file exists in the reference). Not a reference scene.
-inline SceneRecipe big_scene(uint64_t scene_seed, uint32_t n_spheres, uint32_t mesh_subdiv) {
+inline SceneRecipe big_scene(uint64_t scene_seed, uint32_t n_spheres, uint32_t mesh_subdiv, const char* obj_path = nullptr) {
     SceneRng g(scene_seed);
     HittableList world;
     world.add(XzRect::construct(-600, 600, -600, 600, 0, Lambertian::construct(Color3(0.5, 0.5, 0.5))));
@@ -410,8 +451,9 @@ inline SceneRecipe big_scene(uint64_t scene_seed, uint32_t n_spheres, uint32_t m
         else if (choose_mat < 0.95) { const Color3 al = Color3::random_range(g, 0.5, 1); const double fz = g.random_double_range(0, 0.5); world.add(Sphere::construct(c, r, Metal::construct(al, fz))); }
         else world.add(Sphere::construct(c, r, Dielectric::construct(1.5)));
     }
+    if (obj_path && obj_path[0]) load_obj(obj_path, Metal::construct(Color3(0.8, 0.7, 0.3), 0.05), 1.0, Vec3(0, 0, 0), world);
     // torus mesh: major radius 30, minor 10, centred at (0, 12, 0); 2*nu*nv triangles
-    if (mesh_subdiv > 0) {
+    else if (mesh_subdiv > 0) {
         const uint32_t nu = mesh_subdiv, nv = mesh_subdiv / 2 > 3 ? mesh_subdiv / 2 : 3;
         auto mat = Metal::construct(Color3(0.8, 0.7, 0.3), 0.05);
         auto P = [&](uint32_t iu, uint32_t iv) {

@@ -168,3 +168,11 @@ def test_config5_million_spheres_and_mesh(pkg, orc, gpu):
     # (the culling test uses the running closest hit, so which of two hits ~1e-5 apart survives can depend on order)
     img2, _ = gpu.render(gpu.upload(ref_scene.desc), cam, prm)
     assert (np.abs(img - img2).max(axis=2) > 0).mean() < 2e-3
+
+
+def test_imported_obj_mesh(pkg, orc, gpu, tmp_path):
+    from test_host import CUBE_OBJ
+    path = tmp_path / "cube.obj"
+    path.write_text(CUBE_OBJ)
+    hs = pkg.HostScene("obj:" + str(path), 1)
+    check(pkg, orc, gpu, hs.desc, hs.camera(1.5), 96, 64, 8)

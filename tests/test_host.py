@@ -142,3 +142,38 @@ def test_untile(pkg, world):
     out = pkg.untile(prm, np.concatenate(bufs)) if world > 1 else None
     if world > 1:
         assert np.array_equal(out.reshape(-1, 3), full)
+
+
+CUBE_OBJ = """# unit cube, quads + a triangle fan, mixed index forms
+v -1 -1 -1
+v  1 -1 -1
+v  1  1 -1
+v -1  1 -1
+v -1 -1  1
+v  1 -1  1
+v  1  1  1
+v -1  1  1
+vn 0 0 1
+f 1 2 3 4
+f 5/1/1 6/2/1 7/3/1 8/4/1
+f 1//1 2//1 6//1 5//1
+f -6 -5 -1 -2
+f 2 3 7
+f 2 7 6
+f 1 4 8 5
+"""
+
+
+def test_obj_loader(pkg, tmp_path):
+    A = pkg._abi
+    path = tmp_path / "cube.obj"
+    path.write_text(CUBE_OBJ)
+    hs = pkg.HostScene("obj:" + str(path), 1)
+    d = hs.desc
+    info = pkg.compile_info(d)
+    assert info["n_tris"] == 12 and info["n_rects"] == 1            # 5 quads (2 each) + 2 triangles; the ground
+    tris = [d.hittables[i] for i in range(d.n_hittables) if d.hittables[i].kind == A.RT_HIT_TRIANGLE]
+    assert tuple(tris[0].p[:9]) == (-1, -1, -1, 1, -1, -1, 1, 1, -1)  # f 1 2 3 (first fan triangle of the first quad)
+    assert tuple(tris[6].p[:9]) == (1, 1, -1, -1, 1, -1, -1, 1, 1)    # f -6 -5 -1 -2 -> v3 v4 v8 v7: first fan triangle
+    with pytest.raises(pkg.RtError):
+        pkg.HostScene("obj:" + str(tmp_path / "missing.obj"), 1)
