@@ -35,13 +35,12 @@ struct SceneDev {
 
 // Path pool: structure of arrays, one 16-byte lane-contiguous record per array and slot.
 //   ray_o = (origin.xyz, time)         ray_d = (direction.xyz, -)         hit = (t, primitive id)
-//   s0 = (T.rgb, L.r)  s1 = (L.gb, acc.rg)  s2 = (acc.b, work item, sample<<8|depth, x|y<<16)
-//   s3 = rng counter (u64)
-// 104 bytes per path: T = throughput, L = radiance of the current sample, acc = sum over the finished
-// samples of the current work item.
+//   s0 = (T.rgb, sample<<8|depth)   s1 = (acc.rgb, work item)   s2 = x|y<<16   s3 = rng counter (u64)
+// 84 bytes per path (+ 8 for the hit): T = throughput of the sample in flight, acc = sum over the finished
+// samples of the current work item. The radiance of the sample in flight needs no slot (kernels.hip PathState).
 struct PoolDev {
     rtd::Float4* ray_o; rtd::Float4* ray_d; uint2* hit;
-    rtd::Float4* s0; rtd::Float4* s1; rtd::Float4* s2; uint2* s3;
+    rtd::Float4* s0; rtd::Float4* s1; uint32_t* s2; uint2* s3;
 };
 
 struct RenderDev {

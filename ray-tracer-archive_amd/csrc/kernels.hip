@@ -390,8 +390,7 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
                     a = len2(d);
                     if (FEAT & F_XFORM) { ow = o; dw = d; }
                     if (FEAT & F_MEDIUM) {
-                        const Float4 s2 = pool.s2[slot];
-                        const uint32_t sd = __float_as_uint(s2.z), xy = __float_as_uint(s2.w);
+                        const uint32_t sd = __float_as_uint(pool.s0[slot].w), xy = pool.s2[slot];
                         seg = sd & 0xFFu;
                         mkey = path_base(rd.seed, (uint64_t)(xy >> 16) * rd.width + (xy & 0xFFFFu), sd >> 8);
                     }
@@ -620,8 +619,12 @@ DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t s
     tm = g.range(rd.cam_time0, rd.cam_time1);                    // drawn even when time0 == time1
 }
 
+// L, the radiance of the sample in flight, is not part of the state: `emitted` is non-zero only for
+// DiffuseLight, which never scatters (material.rs:12-14,184-190), and the background is returned on a miss
+// (main.rs:74-76) — so radiance is only ever added by the event that ENDS the path, in the same k_shade call
+// that folds it into `acc`.
 struct PathState {
-    V3 T, L, acc;
+    V3 T, acc;
     uint32_t work, sdepth, xy;   // sdepth = sample index << 8 | depth;  xy = x | y << 16
     uint32_t from;               // primitive id the ray starts on (hit-record id), 0 = none
     uint64_t rng;
@@ -629,9 +632,9 @@ struct PathState {
 DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const PathState& s) {
     p.ray_o[i] = Float4{o.x, o.y, o.z, tm};
     p.ray_d[i] = Float4{d.x, d.y, d.z, __uint_as_float(s.from)};
-    p.s0[i] = Float4{s.T.x, s.T.y, s.T.z, s.L.x};
-    p.s1[i] = Float4{s.L.y, s.L.z, s.acc.x, s.acc.y};
-    p.s2[i] = Float4{s.acc.z, __uint_as_float(s.work), __uint_as_float(s.sdepth), __uint_as_float(s.xy)};
+    p.s0[i] = Float4{s.T.x, s.T.y, s.T.z, __uint_as_float(s.sdepth)};
+    p.s1[i] = Float4{s.acc.x, s.acc.y, s.acc.z, __uint_as_float(s.work)};
+    p.s2[i] = s.xy;
     p.s3[i] = make_uint2((uint32_t)s.rng, (uint32_t)(s.rng >> 32));
 }
 
@@ -660,7 +663,7 @@ DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, V3& o, V3
     Rng g;
     const uint32_t sample = it.blk << rd.block_shift;
     new_camera_ray(rd, it.x, it.y, sample, g, o, d, tm);
-    s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); s.acc = v3(0, 0, 0);
+    s.T = v3(1, 1, 1); s.acc = v3(0, 0, 0);
     s.work = work; s.sdepth = sample << 8; s.xy = it.x | (it.y << 16); s.rng = g.s; s.from = 0u;
 }
 
@@ -799,11 +802,12 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     unsigned long long c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
     bool want_work = false;
     if (alive) {
-        const Float4 ro = in.ray_o[i], rdv = in.ray_d[i], s0 = in.s0[i], s1 = in.s1[i], s2 = in.s2[i];
+        const Float4 ro = in.ray_o[i], rdv = in.ray_d[i], s0 = in.s0[i], s1 = in.s1[i];
         const uint2 s3 = in.s3[i], hit = in.hit[i];
         o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
-        s.T = v3(s0.x, s0.y, s0.z); s.L = v3(s0.w, s1.x, s1.y); s.acc = v3(s1.z, s1.w, s2.x);
-        s.work = __float_as_uint(s2.y); s.sdepth = __float_as_uint(s2.z); s.xy = __float_as_uint(s2.w);
+        s.T = v3(s0.x, s0.y, s0.z); s.sdepth = __float_as_uint(s0.w);
+        s.acc = v3(s1.x, s1.y, s1.z); s.work = __float_as_uint(s1.w); s.xy = in.s2[i];
+        V3 L = v3(0.f, 0.f, 0.f);          // radiance of this sample: set by the terminal event only
         s.rng = (uint64_t)s3.x | ((uint64_t)s3.y << 32);
         Rng g; g.s = s.rng;
         uint32_t depth = s.sdepth & 0xFFu, sample = s.sdepth >> 8;
@@ -817,7 +821,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
                 const float t = 0.5f * (ud.y + 1.0f);
                 bg = (1.0f - t) * v3(1.f, 1.f, 1.f) + t * bg;
             }
-            s.L = s.L + s.T * bg;
+            L = s.T * bg;
             finished = true;
         } else {
             // ---- rebuild the HitRecord (hittable.rs:11-19) from (ray, t, primitive) ----
@@ -908,7 +912,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
 
             if (kind == rtd::MK_DIFFUSE_LIGHT) {
                 // emitted (material.rs:184-190); default scatter returns false -> main.rs:85-87
-                if (ff) s.L = s.L + s.T * colour;
+                if (ff) L = s.T * colour;
                 finished = true;
             } else {
                 if (kind == rtd::MK_LAMBERTIAN) {
@@ -978,14 +982,13 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
         if (finished) {
             // one sample done: main.rs:772 `pixel_color += received`
             if (COUNT) c_samples++;
-            V3 L = s.L;
             const bool fin_ok = (fabsf(L.x) < kInf) && (fabsf(L.y) < kInf) && (fabsf(L.z) < kInf);
             if (!fin_ok && rd.nan_policy == RT_NAN_PER_SAMPLE_K) L = v3(0.f, 0.f, 0.f);
             s.acc = s.acc + L;
             sample++;
             if ((sample & ((1u << rd.block_shift) - 1u)) != 0u && sample < rd.spp) {
                 new_camera_ray(rd, s.xy & 0xFFFFu, s.xy >> 16, sample, g, o, d, tm);   // next sample of the same block
-                s.T = v3(1, 1, 1); s.L = v3(0, 0, 0); depth = 0; s.from = 0u;
+                s.T = v3(1, 1, 1); depth = 0; s.from = 0u;
             } else {
                 rd.blocksum[s.work] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
                 want_work = true;

@@ -244,12 +244,12 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     uint32_t P = prm->pool_slots ? prm->pool_slots : (1u << 24);   // rays per launch >> resident lanes, so persistent waves stay fed
     P = (uint32_t)std::min<uint64_t>(P, total_items);
     P = std::max<uint32_t>(256u, (P + 255u) & ~255u);
-    static const size_t rec[7] = {16, 16, 8, 16, 16, 16, 8};
+    static const size_t rec[7] = {16, 16, 8, 16, 16, 4, 8};
     rtk::PoolDev pd[2];
     for (int k = 0; k < 2; ++k) {
         for (int a = 0; a < 7; ++a) HIP_TRY(ctx, ctx->pool[k][a].ensure((size_t)P * rec[a]));
         pd[k].ray_o = (rtd::Float4*)ctx->pool[k][0].p; pd[k].ray_d = (rtd::Float4*)ctx->pool[k][1].p; pd[k].hit = (uint2*)ctx->pool[k][2].p;
-        pd[k].s0 = (rtd::Float4*)ctx->pool[k][3].p; pd[k].s1 = (rtd::Float4*)ctx->pool[k][4].p; pd[k].s2 = (rtd::Float4*)ctx->pool[k][5].p;
+        pd[k].s0 = (rtd::Float4*)ctx->pool[k][3].p; pd[k].s1 = (rtd::Float4*)ctx->pool[k][4].p; pd[k].s2 = (uint32_t*)ctx->pool[k][5].p;
         pd[k].s3 = (uint2*)ctx->pool[k][6].p;
     }
     HIP_TRY(ctx, ctx->blocksum.ensure((size_t)total_items * 16));
