@@ -173,3 +173,31 @@ def test_wrap_records(pkg):
         s = b2.translate(s, (1, 0, 0))
     with pytest.raises(pkg.RtError):
         pkg.compile_info(b2.desc(b2.hittable_list([s])))       # more than 6 wrappers in one chain
+
+
+def test_sah_tree_is_a_valid_accelerator(pkg, orc):
+    """RT_BVH_SAH: the python walk of the dumped tree finds the oracle's closest hit on every ray, with fewer visits."""
+    A = pkg._abi
+    rng = np.random.default_rng(21)
+    visits = {}
+    for builder in (A.RT_BVH_REFERENCE, A.RT_BVH_SAH):
+        b = pkg.SceneBuilder(bvh_seed=5, bvh_builder=builder)
+        m = b.lambertian((0.5, 0.5, 0.5))
+        r2 = np.random.default_rng(8)
+        ids = [b.sphere(r2.uniform(-10, 10, 3) * [1, 0.2, 1], r2.uniform(0.1, 0.8), m) for _ in range(300)] + [b.sphere((0, -1000, 0), 998, m)]
+        desc = b.desc(b.bvh(ids))
+        nodes, spheres, _ = pkg.compile_dump(desc)
+        assert np.all(nodes["skip"] > np.arange(len(nodes)))
+        total = 0
+        rr = np.random.default_rng(9)
+        for _ in range(120):
+            o = rr.uniform(-12, 12, 3) * [1, 0.3, 1] + [0, 3, 0]
+            d = rr.normal(size=3)
+            t, k, v = traverse(nodes, spheres, o, d)
+            ref = orc.world_hit(desc, o, d)
+            assert (ref is None) == (k < 0)
+            if ref is not None:
+                assert t == pytest.approx(ref["t"], rel=1e-5)
+            total += v
+        visits[builder] = total
+    assert visits[A.RT_BVH_SAH] < 0.8 * visits[A.RT_BVH_REFERENCE]
