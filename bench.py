@@ -160,46 +160,50 @@ def main():
                    "bvh_in_lds": stats_acc[0]["bvh_in_lds"] if stats_acc else 0},
     }
 
-    # ---- roofline of the dominant kernel (k_extend = BVH traversal), rank 0's launches ----
-    # algorithmic bytes per ray segment = V_n*32 + V_p*20 (node and sphere records the reference
-    # algorithm touches, counted on the device in a separate counting pass of the same workload at
-    # 1/10 spp) + 32 (ray read) + 8 (hit write).
-    cprm = pkg.make_params(W, H, max(1, args.spp // 10), max_depth=50, seed=1, flags=A.RT_FLAG_COUNTERS,
-                           tile_size=32 if n_gpus > 1 else 0, shard_index=0, shard_count=n_gpus)
-    tmp = torch.zeros(pkg.output_floats(cprm), dtype=torch.float32, device=dev)
-    cst = ctx.render_device(scene, cam, cprm, tmp.data_ptr())
-    vn = cst["node_tests"] / max(1, cst["segments"])
-    vp = cst["prim_tests"][0] / max(1, cst["segments"])
-    seg_per_sample = cst["segments"] / max(1, cst["samples"])
-    b_seg_trav = vn * NODE_BYTES + vp * SPHERE_BYTES
-    b_seg = b_seg_trav + RAY_BYTES + HIT_BYTES
-    achieved = seg * b_seg / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-    # HBM traffic of k_extend proper: bytes/segment from the committed PMC passes (profiles/r01_pmc_traffic.json:
-    # rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this bench, FETCH doubled for gfx950) x the
-    # segments one launch of THIS run processed. bench.py cannot collect PMC counters on itself.
-    traffic, traffic_src = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        traffic = round(tj["kernels"]["k_extend"]["bytes_per_segment"] * seg / max(1, launches) / 1e6, 3)
-        traffic_src = "MB per launch = 41.7 B/segment (PMC: 32.5 read + 9.2 written, profiles/r01_pmc_traffic.json) x segments_per_launch"
-    except Exception:
-        pass
-    out["roofline"] = {
-        "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "MB/launch", "traffic_source": traffic_src,
-        "algorithmic_mb_per_launch": round(b_seg * seg / max(1, launches) / 1e6, 3),
-        "avg_launch_ms": round(ext_ms / max(1, launches), 4), "launches": launches, "segments_per_launch": round(seg / max(1, launches), 1),
-        "bytes_per_segment": round(b_seg, 1), "node_tests_per_segment": round(vn, 2), "sphere_tests_per_segment": round(vp, 2),
-        "segments_per_sample": round(seg_per_sample, 3),
-        "note": "achieved = algorithmic bytes (node + sphere records the reference-order traversal touches, + ray read + hit write) / k_extend "
-                "time from HIP events; the 24 KB scene is LDS-resident, so measured HBM traffic is the 41.7 B/segment of ray state only: the "
-                "kernel is bound by dependent LDS-read -> slab-test chains, not by HBM (DESIGN.md section 5)",
-        "extend_ms_per_step": round(ext_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
-        # whole-path figure in SURVEY 8(d)'s units: B_sample = sum over segments (V_n*32 + V_p*20 + 128) + 12
-        "whole_path": {"bytes_per_sample": round(seg_per_sample * (b_seg_trav + 128) + 12, 1),
-                       "achieved": round(value * 1e6 * (seg_per_sample * (b_seg_trav + 128) + 12) / 1e9 / n_gpus, 1),
-                       "frac": round(value * 1e6 * (seg_per_sample * (b_seg_trav + 128) + 12) / 1e9 / n_gpus / HBM_PEAK_GBS, 4)},
-    }
+        # ---- roofline of the dominant kernel (k_extend = BVH traversal), rank 0's launches ----
+        # algorithmic bytes per ray segment = V_n*32 + V_p*20 (node and sphere records the reference
+        # algorithm touches, counted on the device in a separate counting pass of the same workload at
+        # 1/10 spp) + 32 (ray read) + 8 (hit write).
+        cprm = pkg.make_params(W, H, max(1, args.spp // 10), max_depth=50, seed=1, flags=A.RT_FLAG_COUNTERS,
+                               tile_size=32 if n_gpus > 1 else 0, shard_index=0, shard_count=n_gpus)
+        tmp = torch.zeros(pkg.output_floats(cprm), dtype=torch.float32, device=dev)
+        cst = ctx.render_device(scene, cam, cprm, tmp.data_ptr())
+        vn = cst["node_tests"] / max(1, cst["segments"])
+        vp = cst["prim_tests"][0] / max(1, cst["segments"])
+        seg_per_sample = cst["segments"] / max(1, cst["samples"])
+        b_seg_trav = vn * NODE_BYTES + vp * SPHERE_BYTES
+        b_seg = b_seg_trav + RAY_BYTES + HIT_BYTES
+        achieved = seg * b_seg / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+        # HBM traffic of k_extend proper: bytes/segment from the committed PMC passes (profiles/r01_pmc_traffic.json:
+        # rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this bench, FETCH doubled for gfx950) x the
+        # segments one launch of THIS run processed. bench.py cannot collect PMC counters on itself.
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = round(tj["kernels"]["k_extend"]["bytes_per_segment"] * seg / max(1, launches) / 1e6, 3)
+            traffic_src = "MB per launch = 41.7 B/segment (PMC: 32.5 read + 9.2 written, profiles/r01_pmc_traffic.json) x segments_per_launch"
+        except Exception:
+            pass
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "MB/launch", "traffic_source": traffic_src,
+            "algorithmic_mb_per_launch": round(b_seg * seg / max(1, launches) / 1e6, 3),
+            "avg_launch_ms": round(ext_ms / max(1, launches), 4), "launches": launches, "segments_per_launch": round(seg / max(1, launches), 1),
+            "bytes_per_segment": round(b_seg, 1), "node_tests_per_segment": round(vn, 2), "sphere_tests_per_segment": round(vp, 2),
+            "segments_per_sample": round(seg_per_sample, 3),
+            "note": "achieved = algorithmic bytes (node + sphere records the reference-order traversal touches, + ray read + hit write) / k_extend "
+                    "time from HIP events; the 24 KB scene is LDS-resident, so measured HBM traffic is the 41.7 B/segment of ray state only: the "
+                    "kernel is bound by dependent LDS-read -> slab-test chains, not by HBM (DESIGN.md section 5)",
+            "extend_ms_per_step": round(ext_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
+            # whole-path figure in SURVEY 8(d)'s units: B_sample = sum over segments (V_n*32 + V_p*20 + 128) + 12
+            "whole_path": {"bytes_per_sample": round(seg_per_sample * (b_seg_trav + 128) + 12, 1),
+                           "achieved": round(value * 1e6 * (seg_per_sample * (b_seg_trav + 128) + 12) / 1e9 / n_gpus, 1),
+                           "frac": round(value * 1e6 * (seg_per_sample * (b_seg_trav + 128) + 12) / 1e9 / n_gpus / HBM_PEAK_GBS, 4)},
+        }
+
+    except Exception as e:   # the contract line must survive a failure in the extras
+        out["roofline"] = {"bound": "hbm", "error": repr(e)}
 
     # ---- same workload on the RT_BVH_SAH tree (library option, not the reference's builder): reported beside, never as `value` ----
     if n_gpus == 1:
@@ -218,21 +222,24 @@ def main():
         except Exception as e:   # never let the extra line break the contract line
             out["variants"] = {"bvh_sah": {"error": str(e)}}
 
-    # ---- CPU baseline: the oracle (a port of the reference's CPU path), all host cores, bounded sample ----
-    if n_gpus == 1 and args.cpu_seconds > 0:
-        from oracle import binding as orc
-        cores = host_cores()
-        bw, bh = 1200, 800
-        bcam = hs.camera(bw / bh)
-        probe = pkg.make_params(bw, bh, 2, max_depth=50, seed=1)
-        _, pst = orc.render(hs.desc, bcam, probe, precision=64, n_threads=cores)
-        rate = pst["samples"] / max(pst["seconds"], 1e-6)
-        spp_b = int(max(2, min(args.spp, args.cpu_seconds * rate / (bw * bh))))
-        bprm = pkg.make_params(bw, bh, spp_b, max_depth=50, seed=1)
-        _, bst = orc.render(hs.desc, bcam, bprm, precision=64, n_threads=cores)
-        out["cpu_baseline"] = {"value": round(bst["samples"] / bst["seconds"] / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                               "sample": f"same scene/camera/seed at {bw}x{bh}, {spp_b} spp ({bst['samples']} samples, {bst['seconds']:.1f} s), "
-                                         f"f64 oracle (oracle/oracle.cpp), std::thread over rows"}
+    try:
+        # ---- CPU baseline: the oracle (a port of the reference's CPU path), all host cores, bounded sample ----
+        if n_gpus == 1 and args.cpu_seconds > 0:
+            from oracle import binding as orc
+            cores = host_cores()
+            bw, bh = 1200, 800
+            bcam = hs.camera(bw / bh)
+            probe = pkg.make_params(bw, bh, 2, max_depth=50, seed=1)
+            _, pst = orc.render(hs.desc, bcam, probe, precision=64, n_threads=cores)
+            rate = pst["samples"] / max(pst["seconds"], 1e-6)
+            spp_b = int(max(2, min(args.spp, args.cpu_seconds * rate / (bw * bh))))
+            bprm = pkg.make_params(bw, bh, spp_b, max_depth=50, seed=1)
+            _, bst = orc.render(hs.desc, bcam, bprm, precision=64, n_threads=cores)
+            out["cpu_baseline"] = {"value": round(bst["samples"] / bst["seconds"] / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                                   "sample": f"same scene/camera/seed at {bw}x{bh}, {spp_b} spp ({bst['samples']} samples, {bst['seconds']:.1f} s), "
+                                             f"f64 oracle (oracle/oracle.cpp), std::thread over rows"}
+    except Exception as e:
+        out["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
