@@ -36,6 +36,17 @@ inline uint32_t make_leaf(uint32_t type, uint32_t first, uint32_t count) { retur
 
 // A node without a box (list members, wrappers) stores mn.x = -inf: the slab test passes and the
 // node is not counted as an Aabb::hit.
+//
+// The DEVICE copy of the array (rt_api.cpp: device_nodes) holds the same records regrouped for the
+// kernel: a = (mn.x, mn.y, mx.x, mx.y), b = (mn.z, mx.z, skip * 32, leaf) — one visit is then three
+// packed FMAs (v_pk_fma_f32) and `skip` is already the byte offset of the next record. One extra
+// record closes the array (index n_nodes): no box, skip to itself, leaf = LEAF_DONE, so a lane that has
+// walked off the end parks there and k_extend's node step needs no bounds test.
+struct NodeDev { float mnx, mny, mxx, mxy, mnz, mxz; uint32_t skip_bytes, leaf; };
+static_assert(sizeof(NodeDev) == 32, "device node record is 32 bytes");
+// lane states of k_extend kept in the `pend` word (leaf type 0 = no primitive work):
+constexpr uint32_t LEAF_IDLE = 1u << 24;   // the lane holds no ray
+constexpr uint32_t LEAF_DONE = 2u << 24;   // the lane's ray has visited every node
 
 // ---- primitives: one geometry array per type (16-byte records) + one u32 `meta` per primitive ----
 // meta = material id (22 bits) | wrap id << 22 (10 bits)

@@ -62,7 +62,8 @@ struct RenderDev {
 };
 
 struct LaunchCfg {
-    uint32_t extend_blocks;   // persistent grid
+    uint32_t n_cu;            // k_extend runs as a persistent grid: n_cu x (resident workgroups per CU)
+    uint32_t* extend_geometry;   // optional out: resident workgroups per CU for 256- and 512-thread groups
     uint32_t features;        // F_* the scene needs
     bool scene_in_lds;
 };

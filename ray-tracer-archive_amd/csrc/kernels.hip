@@ -285,6 +285,13 @@ DEVI bool medium_hit(const SceneDev& sc, const rtd::Medium& m, V3 ow, V3 dw, flo
 // ------------------------------------------------------------------------------------------------
 // k_extend — world.hit for the whole pool
 // ------------------------------------------------------------------------------------------------
+typedef float F2 __attribute__((ext_vector_type(2)));
+// per-ray constants of the slab test t = n * (1/d) - o/d. Culling only: boxes carry the slack (scene_compile.cpp)
+DEVI void set_slab_ray(V3 o, V3 d, F2& inv_xy, F2& inv_zz, F2& noi_xy, F2& noi_zz) {
+    const V3 inv = v3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+    inv_xy = F2{inv.x, inv.y}; inv_zz = F2{inv.z, inv.z};
+    noi_xy = F2{-(o.x * inv.x), -(o.y * inv.y)}; noi_zz = F2{-(o.z * inv.z), -(o.z * inv.z)};
+}
 #ifndef RT_CHUNK
 #define RT_CHUNK 256        // rays a wave takes from the queue head per atomic
 #endif
@@ -311,8 +318,8 @@ constexpr int kLeafBatch = RT_LEAF_BATCH;
 // in separate passes so that each pass keeps many lanes busy: a primitive test (f64 refinement) costs
 // several node visits, and in lock step with node visits it would run with one or two active lanes.
 // Per lane the ORDER of events is unchanged: the leaf is tested before the lane visits its next node.
-template <bool LDS, uint32_t FEAT, bool COUNT>
-__global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
+template <bool LDS, uint32_t FEAT, bool COUNT, uint32_t TPB>
+__global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
                                                  uint32_t* __restrict__ head, uint32_t* __restrict__ count_out_to_zero,
                                                  unsigned long long* __restrict__ counters, RenderDev rd) {
     extern __shared__ float4 lds[];
@@ -324,7 +331,7 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
         // stage the node records and the sphere records (the whole BVH for book-1-sized scenes): a linear
         // copy, i.e. exactly the shape of LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, LDS
         // address = wave base + lane * 16, no VGPR round trip); all pieces in flight, then one wait + barrier
-        const uint32_t n4 = 2 * n_nodes, s4 = sc.n_spheres, tot = n4 + s4;      // nodes then spheres, contiguous in LDS
+        const uint32_t n4 = 2 * (n_nodes + 1u), s4 = sc.n_spheres, tot = n4 + s4;   // nodes (+ closing record) then spheres, contiguous in LDS
         const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63u, nw = blockDim.x >> 6;
         for (uint32_t base = wave * 64u; base < tot; base += nw * 64u) {
             const uint32_t i = base + ln;
@@ -351,9 +358,13 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
     const uint32_t head0 = n_waves * chunk;         // the dynamic part of the queue starts behind the static chunks
 
     bool have = false;
-    uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE, pend = 0, from = 0;
+    // `node` is the BYTE offset of the lane's next node record; `pend` is 0 while the lane walks, else the leaf word it
+    // waits with (or LEAF_IDLE / LEAF_DONE): one compare tells whether the lane takes part in a node step
+    const uint32_t end_off = n_nodes * 32u;
+    uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE, pend = rtd::LEAF_IDLE, from = 0;
     float tmax = kInf, tm = 0.f, a = 1.f;
-    V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0), oi = v3(0, 0, 0);
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
+    F2 inv_xy = {0.f, 0.f}, inv_zz = {0.f, 0.f}, noi_xy = {0.f, 0.f}, noi_zz = {0.f, 0.f};   // 1/d and -o/d, paired for v_pk_fma_f32
     V3 ow = o, dw = d;                 // world ray while inside an instance transform
     uint64_t mkey = 0; uint32_t seg = 0;
     unsigned long long c_nodes = 0, c_prims[RT_N_PRIM_TYPES_K] = {0, 0, 0, 0, 0, 0};
@@ -385,8 +396,7 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
                     slot = w_next + rank;
                     o = v3(ox, oy, oz); d = v3(dx, dy, dz); tm = ot;
                     from = __float_as_uint(dfrom);            // primitive this ray starts on (0: camera / medium)
-                    inv = v3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));   // culling only: boxes carry the slack (scene_compile.cpp)
-                    oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+                    set_slab_ray(o, d, inv_xy, inv_zz, noi_xy, noi_zz);
                     a = len2(d);
                     if (FEAT & F_XFORM) { ow = o; dw = d; }
                     if (FEAT & F_MEDIUM) {
@@ -425,31 +435,34 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
 #ifdef RT_STAMPS
         STAMP(st_b);
 #endif
-        // ---- node pass: branch-free steps. A lane that is not walking (no ray, holding a leaf, or past the
-        // last node) re-reads node 0 and keeps its state; everything is a select, so a step is ~30 VALU, two
-        // ds_read_b128 and no exec-mask traffic. ----
+        // ---- node pass: branch-free steps. A lane that is not walking (no ray, holding a leaf, done) re-reads
+        // record 0 and keeps its state; everything is a select: ~22 VALU, two ds_read_b128, no exec-mask traffic.
+        // The array ends with a box-less record that skips to itself and carries LEAF_DONE, so a lane that walks off
+        // the end parks by itself. Boxes carry the rounding slack of this test (scene_compile.cpp: pad_scale). ----
 #pragma unroll
         for (int step = 0; step < kSteps; ++step) {
-            const bool walk = have && pend == 0u && node < n_nodes;
-            const uint32_t idx = walk ? node : 0u;
-            const float4 n0 = nodes[2 * idx], n1 = nodes[2 * idx + 1];
-            const uint32_t skip = __float_as_uint(n0.w), leaf = __float_as_uint(n1.w);
+            const bool walk = pend == 0u;
+            const uint32_t off = walk ? node : 0u;
+            const float4 n0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off);
+            const float4 n1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off + 16u);
+            const uint32_t skip = __float_as_uint(n1.z), leaf = __float_as_uint(n1.w);
             // Aabb::hit (aabb.rs:31-55, interval carried across axes). min/max ignore a NaN
             // operand (0*inf), which keeps the box — conservative, like the reference.
-            const float tx0 = fmaf(n0.x, inv.x, -oi.x), tx1 = fmaf(n1.x, inv.x, -oi.x);
-            const float ty0 = fmaf(n0.y, inv.y, -oi.y), ty1 = fmaf(n1.y, inv.y, -oi.y);
-            const float tz0 = fmaf(n0.z, inv.z, -oi.z), tz1 = fmaf(n1.z, inv.z, -oi.z);
-            const float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), kTMin));
-            const float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
-            const bool boxhit = tnear <= tfar * 1.0000004f;   // padded by 3 ulp: never cull a true hit
+            const F2 t_mn = __builtin_elementwise_fma(F2{n0.x, n0.y}, inv_xy, noi_xy);   // (tx0, ty0)
+            const F2 t_mx = __builtin_elementwise_fma(F2{n0.z, n0.w}, inv_xy, noi_xy);   // (tx1, ty1)
+            const F2 t_z = __builtin_elementwise_fma(F2{n1.x, n1.y}, inv_zz, noi_zz);    // (tz0, tz1)
+            const float tnear = fmaxf(fmaxf(fminf(t_mn.x, t_mx.x), fminf(t_mn.y, t_mx.y)), fmaxf(fminf(t_z.x, t_z.y), kTMin));
+            const float tfar = fminf(fminf(fmaxf(t_mn.x, t_mx.x), fmaxf(t_mn.y, t_mx.y)), fminf(fmaxf(t_z.x, t_z.y), tmax));
+            const bool boxhit = tnear <= tfar;
             if (COUNT) c_nodes += (walk && n0.x > -kInf) ? 1ull : 0ull;
-            node = walk ? (boxhit ? node + 1u : skip) : node;
+            const uint32_t next = boxhit ? node + 32u : skip;
+            node = walk ? next : node;
             pend = (walk && boxhit) ? leaf : pend;            // leaf == 0 for an inner node
         }
         // ---- rare events, outside the steps ----
-        if (have && pend == 0u && node >= n_nodes) {          // walked off the end: world.hit is done
+        if (pend == rtd::LEAF_DONE || (pend == 0u && node >= end_off)) {   // walked off the end: world.hit is done
             pool.hit[slot] = make_uint2(__float_as_uint(tmax), hit_prim);
-            have = false;
+            have = false; pend = rtd::LEAF_IDLE;
         }
         if (FEAT & F_XFORM) {
             const uint32_t type = pend >> 28;
@@ -457,8 +470,7 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
                 const uint32_t xf = pend & rtd::LEAF_MAX_FIRST;
                 if (xf == 0u) { o = ow; d = dw; }
                 else xform_ray(sc.xforms[xf], ow, dw, o, d);
-                inv = v3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
-                oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+                set_slab_ray(o, d, inv_xy, inv_zz, noi_xy, noi_zz);
                 if (COUNT) { if (type == rtd::LT_ENTER) c_prims[5]++; }
                 pend = 0u;
             }
@@ -468,9 +480,9 @@ __global__ void __launch_bounds__(kExtendThreads) k_extend(SceneDev sc, PoolDev 
         STAMP(st_a); st_node += st_a - st_b;
 #endif
         // ---- primitive pass: when enough lanes hold a leaf, or nobody can walk any further ----
-        const uint64_t pm = __ballot(pend != 0u);
-        const bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(have && pend == 0u) == 0ull);
-        if (do_prims && pend != 0u) {
+        const uint64_t pm = __ballot((pend >> 28) != 0u);
+        const bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(pend == 0u) == 0ull);
+        if (do_prims && (pend >> 28) != 0u) {
             const uint32_t type = pend >> 28, cnt = (pend >> 24) & 15u, first = pend & rtd::LEAF_MAX_FIRST;
             pend = 0u;
             if (type == rtd::LT_SPHERE) {
@@ -1061,13 +1073,34 @@ __global__ void __launch_bounds__(256) k_write_color(const float* __restrict__ r
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// Persistent grid of k_extend = what is resident at once. Registers and the LDS copy of the scene both
+// limit it; a scene whose LDS copy is large (book-2 final: 65 KB) allows two workgroups per CU, and then
+// 512-thread workgroups keep twice the waves of 256-thread ones. The runtime's occupancy query decides.
+template <bool LDS, uint32_t FEAT, bool COUNT>
+static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
+                                  uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
+    const size_t lds_bytes = LDS ? (((size_t)sc.n_nodes + 1u) * 32u + (size_t)sc.n_spheres * 16u) : 0u;
+    static thread_local size_t cached_lds = ~(size_t)0; static thread_local int nb_small = 0, nb_big = 0;
+    if (cached_lds != lds_bytes) {
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_small, k_extend<LDS, FEAT, COUNT, kExtendThreads>, (int)kExtendThreads, lds_bytes);
+        if (e != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_big, k_extend<LDS, FEAT, COUNT, 2u * kExtendThreads>, (int)(2u * kExtendThreads), lds_bytes);
+        if (e != hipSuccess) return e;
+        if (nb_small < 1) nb_small = 1;
+        cached_lds = lds_bytes;
+    }
+    if (cfg.extend_geometry) { cfg.extend_geometry[0] = (uint32_t)nb_small; cfg.extend_geometry[1] = (uint32_t)nb_big; }
+    if (2 * nb_big > nb_small)
+        hipLaunchKernelGGL((k_extend<LDS, FEAT, COUNT, 2u * kExtendThreads>), dim3(cfg.n_cu * (uint32_t)nb_big), dim3(2u * kExtendThreads), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
+    else
+        hipLaunchKernelGGL((k_extend<LDS, FEAT, COUNT, kExtendThreads>), dim3(cfg.n_cu * (uint32_t)nb_small), dim3(kExtendThreads), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
+    return hipGetLastError();
+}
 template <bool LDS, uint32_t FEAT>
 static hipError_t launch_extend_t(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, bool count, hipStream_t stream) {
-    const size_t lds_bytes = LDS ? ((size_t)sc.n_nodes * 32u + (size_t)sc.n_spheres * 16u) : 0u;
-    if (count) hipLaunchKernelGGL((k_extend<LDS, FEAT, true>), dim3(cfg.extend_blocks * 256u / kExtendThreads), dim3(kExtendThreads), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
-    else hipLaunchKernelGGL((k_extend<LDS, FEAT, false>), dim3(cfg.extend_blocks * 256u / kExtendThreads), dim3(kExtendThreads), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
-    return hipGetLastError();
+    return count ? launch_extend_c<LDS, FEAT, true>(cfg, sc, pool, rd, count_ptr, head, cz, counters, stream)
+                 : launch_extend_c<LDS, FEAT, false>(cfg, sc, pool, rd, count_ptr, head, cz, counters, stream);
 }
 
 // Kernel variants are compiled for a few feature sets; a scene runs on the smallest one that covers it.

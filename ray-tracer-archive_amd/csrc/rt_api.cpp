@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -142,6 +143,18 @@ int rt_ctx_destroy(RtCtx* ctx) {
     return RT_OK;
 }
 
+// device layout of the threaded BVH (device_types.h: NodeDev) + the closing record
+static std::vector<rtd::NodeDev> device_nodes(const std::vector<rtd::Node>& nodes) {
+    std::vector<rtd::NodeDev> out(nodes.size() + 1);
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const rtd::Node& n = nodes[i];
+        out[i] = rtd::NodeDev{n.mn[0], n.mn[1], n.mx[0], n.mx[1], n.mn[2], n.mx[2], n.skip * 32u, n.leaf};
+    }
+    const float inf = std::numeric_limits<float>::infinity();
+    out[nodes.size()] = rtd::NodeDev{-inf, -inf, inf, inf, -inf, inf, (uint32_t)nodes.size() * 32u, rtd::LEAF_DONE};
+    return out;
+}
+
 int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
     if (!desc || !out_scene) return set_err(ctx, RT_ERR_INVALID, "desc / out_scene is null");
@@ -153,7 +166,8 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     RtScene* s = new RtScene();
     int r = RT_OK;
     auto up = [&](auto& buf, const auto& vec) { if (r == RT_OK) r = upload(ctx, buf, vec); };
-    up(s->nodes, cs.nodes); up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
+    const std::vector<rtd::NodeDev> dnodes = device_nodes(cs.nodes);   // alive until the stream sync below
+    up(s->nodes, dnodes); up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
     up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->media, cs.media);
     up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
     up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
@@ -172,7 +186,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     d.lights = (const rtd::Light*)s->lights.p; d.n_lights = (uint32_t)cs.lights.size();
     const uint32_t f = scene_features(cs);
     s->features = f;
-    const size_t lds_bytes = cs.nodes.size() * 32 + cs.spheres.size() * 16;
+    const size_t lds_bytes = (cs.nodes.size() + 1) * 32 + cs.spheres.size() * 16;
     s->in_lds = lds_bytes <= kLdsSceneBudget; s->lds_bytes = lds_bytes;
     s->bg_mode = cs.background_mode; for (int i = 0; i < 3; ++i) s->bg[i] = cs.background[i];
     s->n_nodes = cs.nodes.size();
@@ -271,11 +285,8 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
 
     const bool counting = (prm->flags & RT_FLAG_COUNTERS) != 0, timing = (prm->flags & RT_FLAG_TIMING) != 0;
     rtk::LaunchCfg cfg{};
-    // persistent grid = what is resident at once: 8 workgroups of 256 per CU by registers, fewer when the
-    // LDS copy of the scene (nodes + sphere records) limits it
-    uint32_t per_cu = 8u;
-    if (scene->in_lds) per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (uint32_t)((160u * 1024u) / std::max<uint64_t>(1024u, scene->lds_bytes))));
-    cfg.extend_blocks = (uint32_t)ctx->n_cu * per_cu; cfg.features = scene->features; cfg.scene_in_lds = scene->in_lds;
+    uint32_t extend_geometry[2] = {0u, 0u};
+    cfg.n_cu = (uint32_t)ctx->n_cu; cfg.extend_geometry = extend_geometry; cfg.features = scene->features; cfg.scene_in_lds = scene->in_lds;
 
     size_t ev_used = 0;
     auto next_event = [&](hipEvent_t& ev) -> hipError_t {
@@ -335,6 +346,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
             for (int k = 0; k < RT_N_PRIM_TYPES; ++k) stats->prim_tests[k] = ctx->h_counters[rtk::CTR_PRIM_TESTS + k];
         }
         for (int k = 0; k < 5; ++k) stats->debug[k] = ctx->h_counters[rtk::CTR_DEBUG + k];
+        stats->debug[6] = extend_geometry[0]; stats->debug[7] = extend_geometry[1];   // resident k_extend groups per CU (256 / 512 threads)
         stats->iterations = (uint32_t)ctx->h_counters[rtk::CTR_ITERATIONS]; stats->extend_launches = launched; stats->shade_launches = launched; stats->pool_slots = P;
         stats->scene_nodes = scene->n_nodes; stats->scene_prims = scene->n_prims; stats->scene_bytes = scene->bytes; stats->bvh_in_lds = scene->in_lds ? 1u : 0u;
     }
@@ -409,7 +421,7 @@ int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out) {
     out->n_rects = cs.rect_meta.size(); out->n_tris = cs.tri_meta.size(); out->n_media = cs.media.size(); out->n_xforms = cs.xforms.size();
     out->n_lights = cs.lights.size(); out->n_materials = cs.mat_b.size();
     out->features = scene_features(cs);
-    out->fits_lds = (cs.nodes.size() * 32 + cs.spheres.size() * 16) <= kLdsSceneBudget ? 1u : 0u;
+    out->fits_lds = ((cs.nodes.size() + 1) * 32 + cs.spheres.size() * 16) <= kLdsSceneBudget ? 1u : 0u;
     return RT_OK;
 }
 
