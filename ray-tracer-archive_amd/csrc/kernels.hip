@@ -20,6 +20,7 @@
 //
 // No MFMA: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include "device_types.h"
@@ -324,6 +325,17 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                                                  unsigned long long* __restrict__ counters, RenderDev rd) {
     extern __shared__ float4 lds[];
     if (blockIdx.x == 0 && threadIdx.x == 0) *count_out_to_zero = 0u;   // the next k_shade appends to it
+    const uint32_t count = *count_ptr;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    uint32_t chunk = count > kChunk * n_waves ? kChunk : max(64u, (count / (2u * n_waves)) & ~63u);
+    // the first chunk of every wave is static (wave w owns [w*chunk, (w+1)*chunk)); the queue head counts from
+    // behind them. Otherwise every wave of the grid would hit the head with a returning atomic in the same
+    // microsecond (same-address atomics serialise, ~11 ns each).
+    const uint32_t head0 = n_waves * chunk;         // the dynamic part of the queue starts behind the static chunks
+    // Short queue (the long tail of a render, hundreds of launches with a few thousand rays): a workgroup whose
+    // waves own no static chunk has no dynamic chunk to fetch either — leave before staging the scene.
+    if (blockIdx.x * (blockDim.x >> 6) * chunk >= count && head0 >= count) return;
     const uint32_t n_nodes = sc.n_nodes;
     const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
     const float4* spheres = reinterpret_cast<const float4*>(sc.spheres);
@@ -345,17 +357,9 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         __syncthreads();
         nodes = lds; spheres = lds + n4;
     }
-    const uint32_t count = *count_ptr;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    uint32_t chunk = count > kChunk * n_waves ? kChunk : max(64u, (count / (2u * n_waves)) & ~63u);
-    // the first chunk of every wave is static (wave w owns [w*chunk, (w+1)*chunk)); the queue head counts from
-    // behind them. Otherwise every wave of the grid would hit the head with a returning atomic in the same
-    // microsecond (same-address atomics serialise, ~11 ns each).
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     uint32_t w_next = min(wave_id * chunk, count), w_end = min(w_next + chunk, count);
     bool exhausted = false;
-    const uint32_t head0 = n_waves * chunk;         // the dynamic part of the queue starts behind the static chunks
 
     bool have = false;
     // `node` is the BYTE offset of the lane's next node record; `pend` is 0 while the lane walks, else the leaf word it
@@ -1087,6 +1091,9 @@ static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, cons
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_big, k_extend<LDS, FEAT, COUNT, 2u * kExtendThreads>, (int)(2u * kExtendThreads), lds_bytes);
         if (e != hipSuccess) return e;
         if (nb_small < 1) nb_small = 1;
+#ifdef RT_EXTEND_PER_CU_MAX
+        nb_small = std::min(nb_small, RT_EXTEND_PER_CU_MAX); nb_big = std::min(nb_big, RT_EXTEND_PER_CU_MAX / 2);   // tuning builds only
+#endif
         cached_lds = lds_bytes;
     }
     if (cfg.extend_geometry) { cfg.extend_geometry[0] = (uint32_t)nb_small; cfg.extend_geometry[1] = (uint32_t)nb_big; }

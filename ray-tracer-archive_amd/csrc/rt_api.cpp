@@ -237,13 +237,14 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         prefix[lt + 1] = prefix[lt] + w * h;
     }
     const uint64_t valid_pixels = prefix[tl.n_local];
-    // samples per work item: a power of two, 16 unless that makes more than 2^31 items
-    uint32_t block_shift = 4;
-    while ((1u << block_shift) > rd.spp && block_shift > 0) --block_shift;
-    for (;;) {
-        const uint64_t nb = (rd.spp + (1u << block_shift) - 1) >> block_shift;
-        if (valid_pixels * nb < (1ull << 31) || (1u << block_shift) >= rd.spp) break;
-        ++block_shift;
+    // samples per work item: 1 whenever the whole IMAGE (all shards, so that every shard sums the same way) has at most
+    // 2^30 samples — a path is then one sample, nothing is regenerated mid-flight and the radiance of every sample
+    // is stored on its own (16 GB of block sums at the limit; this is a 288 GB device). Larger renders group 2, 4, ...
+    // consecutive samples of a pixel into one item.
+    uint32_t block_shift = 0;
+    {
+        const uint64_t image_pixels = (uint64_t)prm->width * prm->height;
+        while ((1u << block_shift) < rd.spp && image_pixels * ((rd.spp + (1u << block_shift) - 1) >> block_shift) > (1ull << 30)) ++block_shift;
     }
     rd.block_shift = block_shift; rd.n_blocks = (rd.spp + (1u << block_shift) - 1) >> block_shift;
     const uint64_t total_items = valid_pixels * rd.n_blocks;
@@ -255,10 +256,22 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     const auto t_begin = clk::now();
     if (total_items == 0) { if (stats) stats->render_ms = 0.0; return RT_OK; }
 
-    uint32_t P = prm->pool_slots ? prm->pool_slots : (1u << 24);   // rays per launch >> resident lanes, so persistent waves stay fed
-    P = (uint32_t)std::min<uint64_t>(P, total_items);
-    P = std::max<uint32_t>(256u, (P + 255u) & ~255u);
+    // Pool: as many paths in flight as there are work items, up to 2^28 (45 GB for the two pools) and to what the
+    // device has free. Launches then carry hundreds of millions of rays: few launches, short tails.
     static const size_t rec[7] = {16, 16, 8, 16, 16, 4, 8};
+    size_t slot_bytes = 0; for (int a = 0; a < 7; ++a) slot_bytes += 2 * rec[a];
+    uint32_t P = prm->pool_slots ? prm->pool_slots : (1u << 28);
+    P = (uint32_t)std::min<uint64_t>(P, total_items);
+    if (!prm->pool_slots) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            size_t held = ctx->blocksum.bytes; for (int k = 0; k < 2; ++k) for (int a = 0; a < 7; ++a) held += ctx->pool[k][a].bytes;
+            const size_t avail = free_b + held, need_sum = (size_t)total_items * 16;
+            const size_t budget = avail * 7 / 10 > need_sum ? avail * 7 / 10 - need_sum : 0;
+            while (P > (1u << 20) && (size_t)P * slot_bytes > budget) P >>= 1;
+        }
+    }
+    P = std::max<uint32_t>(256u, (P + 255u) & ~255u);
     rtk::PoolDev pd[2];
     for (int k = 0; k < 2; ++k) {
         for (int a = 0; a < 7; ++a) HIP_TRY(ctx, ctx->pool[k][a].ensure((size_t)P * rec[a]));

@@ -22,6 +22,15 @@ VARIANTS = {
     "b24": ["RT_LEAF_BATCH=24"],
     "b32": ["RT_LEAF_BATCH=32"],
     "b1": ["RT_LEAF_BATCH=1"],
+    "bs0": ["RT_BLOCK_SHIFT=0"],
+    "bs1": ["RT_BLOCK_SHIFT=1"],
+    "bs2": ["RT_BLOCK_SHIFT=2"],
+    "bs3": ["RT_BLOCK_SHIFT=3"],
+    "bs5": ["RT_BLOCK_SHIFT=5"],
+    "o5": ["RT_EXTEND_PER_CU_MAX=5"],
+    "o4": ["RT_EXTEND_PER_CU_MAX=4"],
+    "o3": ["RT_EXTEND_PER_CU_MAX=3"],
+    "o2": ["RT_EXTEND_PER_CU_MAX=2"],
 }
 if sys.argv[1] == "build":
     import importlib.util
