@@ -13,7 +13,7 @@ RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT, RT_MAT
 RT_BG_CONSTANT, RT_BG_SKY_GRADIENT = 0, 1
 RT_BVH_REFERENCE, RT_BVH_SAH = 0, 1
 RT_NAN_PER_SAMPLE, RT_NAN_REFERENCE = 0, 1
-RT_FLAG_COUNTERS, RT_FLAG_TIMING = 1, 2
+RT_FLAG_COUNTERS, RT_FLAG_TIMING, RT_FLAG_SAMPLE_BLOCKS = 1, 2, 4
 
 
 class RtVec3(C.Structure):

@@ -44,6 +44,13 @@ inline uint32_t make_leaf(uint32_t type, uint32_t first, uint32_t count) { retur
 // walked off the end parks there and k_extend's node step needs no bounds test.
 struct NodeDev { float mnx, mny, mxx, mxy, mnz, mxz; uint32_t skip_bytes, leaf; };
 static_assert(sizeof(NodeDev) == 32, "device node record is 32 bytes");
+// Record stride. In HBM records are packed. A scene that k_extend keeps in LDS is laid out with 48-byte
+// records (16 bytes of padding): the two 16-byte halves of 32-byte records only ever land on 8 of the 16
+// slot columns of the LDS bank row, which doubles the ds_read_b128 bank conflicts of lanes at different nodes.
+#ifndef RT_NODE_STRIDE_LDS
+#define RT_NODE_STRIDE_LDS 48
+#endif
+constexpr uint32_t NODE_STRIDE_HBM = 32, NODE_STRIDE_LDS = RT_NODE_STRIDE_LDS;
 // lane states of k_extend kept in the `pend` word (leaf type 0 = no primitive work):
 constexpr uint32_t LEAF_IDLE = 1u << 24;   // the lane holds no ray
 constexpr uint32_t LEAF_DONE = 2u << 24;   // the lane's ray has visited every node

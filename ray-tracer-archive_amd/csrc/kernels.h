@@ -40,7 +40,7 @@ struct SceneDev {
 // samples of the current work item. The radiance of the sample in flight needs no slot (kernels.hip PathState).
 struct PoolDev {
     rtd::Float4* ray_o; rtd::Float4* ray_d; uint2* hit;
-    rtd::Float4* s0; rtd::Float4* s1; uint32_t* s2; uint2* s3;
+    rtd::Float4* s0; uint4* s3; rtd::Float4* s1;   // s0 = (T.rgb, work item); s3 = (rng lo, hi, sample << 8 | depth, x | y << 16); s1 = acc (block_shift != 0 only)
 };
 
 struct RenderDev {

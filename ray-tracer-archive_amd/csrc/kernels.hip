@@ -43,22 +43,40 @@ DEVI V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
 DEVI V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
 DEVI V3 operator*(V3 a, float t) { return v3(a.x * t, a.y * t, a.z * t); }
 DEVI V3 operator*(float t, V3 a) { return v3(a.x * t, a.y * t, a.z * t); }
+// Division and square root. The reference is f64; this path is f32 and everything below already differs from it by
+// rounding. The IEEE-exact f32 sequences (v_div_scale/fmas/fixup: 12 instructions; sqrtf: 15) buy nothing against
+// that reference, and the shading kernels are bound by VALU issue, so the hardware approximations are used:
+// v_rcp_f32, v_sqrt_f32, v_rsq_f32, 1 ulp each. x/0 and 0/0 keep their class (inf, NaN). -DRT_IEEE_DIV_SQRT restores
+// the exact sequences (tests/test_gpu_scenes.py compares the two builds' statistics, not bits).
+#ifdef RT_IEEE_DIV_SQRT
+DEVI float fdiv(float a, float b) { return a / b; }
+DEVI float fsqrt(float x) { return sqrtf(x); }
 DEVI V3 operator/(V3 a, float t) { return v3(a.x / t, a.y / t, a.z / t); }   // vec3.rs:181: component-wise divide
+#else
+DEVI float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+DEVI float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+DEVI V3 operator/(V3 a, float t) { const float r = __builtin_amdgcn_rcpf(t); return v3(a.x * r, a.y * r, a.z * r); }   // vec3.rs:181
+#endif
 DEVI float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DEVI V3 cross(V3 u, V3 v) { return v3(u.y * v.z - u.z * v.y, -(u.x * v.z - u.z * v.x), u.x * v.y - u.y * v.x); }   // vec3.rs:68-76
 DEVI float len2(V3 a) { return dot(a, a); }
-DEVI float len(V3 a) { return sqrtf(len2(a)); }
+DEVI float len(V3 a) { return fsqrt(len2(a)); }
+#ifdef RT_IEEE_DIV_SQRT
 DEVI V3 unit(V3 a) { return a / len(a); }                                   // vec3.rs:29-31
+#else
+DEVI V3 unit(V3 a) { const float r = __builtin_amdgcn_rsqf(len2(a)); return v3(a.x * r, a.y * r, a.z * r); }   // vec3.rs:29-31
+#endif
 DEVI V3 reflect(V3 v, V3 n) { return v - 2.0f * dot(v, n) * n; }            // vec3.rs:115-117
 DEVI V3 refract(V3 uv, V3 n, float eta) {                                    // vec3.rs:246-251
     float cos_theta = fminf(dot(-uv, n), 1.0f);
     V3 perp = eta * (uv + cos_theta * n);
-    V3 par = -sqrtf(fabsf(1.0f - len2(perp))) * n;
+    V3 par = -fsqrt(fabsf(1.0f - len2(perp))) * n;
     return perp + par;
 }
 DEVI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp; rcp(+-0) = +-inf
 DEVI float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.31830988618379067154f;
 constexpr float kInf = __builtin_huge_valf();
 constexpr float kTMin = 0.001f;   // main.rs:74
 
@@ -106,16 +124,16 @@ DEVI V3 random_in_unit_sphere(Rng& g) {                                      // 
 }
 DEVI V3 random_cosine_direction(Rng& g) {                                    // vec3.rs:253-262
     float r1 = g.rnd(), r2 = g.rnd();
-    float z = sqrtf(1.0f - r2);
+    float z = fsqrt(1.0f - r2);
     float s, c; sincos_2pi(r1, s, c);                                       // phi = 2*PI*r1
-    float sr = sqrtf(r2);
+    float sr = fsqrt(r2);
     return v3(c * sr, s * sr, z);
 }
 DEVI V3 random_to_sphere(Rng& g, float radius, float distance_sq) {          // pdf.rs:82-91
     float r1 = g.rnd(), r2 = g.rnd();
-    float z = 1.0f + r2 * (sqrtf(1.0f - radius * radius / distance_sq) - 1.0f);
+    float z = 1.0f + r2 * (fsqrt(1.0f - fdiv(radius * radius, distance_sq)) - 1.0f);
     float s, c; sincos_2pi(r1, s, c);                                       // phi = 2*PI*r1
-    float q = sqrtf(1.0f - z * z);
+    float q = fsqrt(1.0f - z * z);
     return v3(c * q, s * q, z);
 }
 struct Onb { V3 u, v, w; };
@@ -164,7 +182,7 @@ DEVI V3 xform_normal_back(const rtd::Xform& x, V3 n) {
 //   3. the two roots come from the cancellation-free pair q/a and c/q in f32.
 DEVI bool sphere_certain_miss(V3 o, V3 d, float a, V3 c, float r) {
     const V3 oc = o - c;
-    const float hb = dot(oc, d), l2 = dot(oc, oc), r2 = r * r;
+    const float hb = fmaf(oc.z, d.z, fmaf(oc.y, d.y, oc.x * d.x)), l2 = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, oc.x * oc.x)), r2 = r * r;
     const float cc = l2 - r2;
     const float det = fmaf(hb, hb, -a * cc);
     const float scale = l2 + r2;
@@ -178,10 +196,10 @@ DEVI bool sphere_roots(V3 o, V3 d, float a, V3 c, float r, float tmin, float tma
     const double det = fma(half_b, half_b, -(double)a * cc);
     if (det < 0.0) return false;
     const float hbf = (float)half_b, ccf = (float)cc;
-    const float sq = sqrtf((float)det);
+    const float sq = __builtin_amdgcn_sqrtf((float)det);     // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the IEEE sequences:
     const float q = hbf > 0.f ? -(hbf + sq) : (sq - hbf);   // -half_b -/+ sqrt(det) without cancellation
     if (q == 0.f) return false;                              // double root at t = 0
-    const float tq = q / a, tc = ccf / q;
+    const float tq = q * fast_rcp(a), tc = ccf * fast_rcp(q);   // the roots carry ~2 ulp, like every f32 quantity around them
     const float t_near = hbf > 0.f ? tq : tc, t_far = hbf > 0.f ? tc : tq;   // (-hb - sq)/a and (-hb + sq)/a
     float root = t_near;
     if (root < tmin || tmax < root) {
@@ -203,20 +221,20 @@ DEVI bool sphere_hit(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax,
 // construction, which is what the f64 reference computes.
 DEVI bool sphere_hit_from_surface(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax, float& t) {
     const V3 oc = o - c;
-    const float root = -2.0f * dot(oc, d) / a;
+    const float root = -2.0f * dot(oc, d) * fast_rcp(a);
     if (root < tmin || tmax < root) return false;
     t = root;
     return true;
 }
 DEVI V3 moving_center(Float4 m0, Float4 m1, Float4 m2, float time) {           // moving_sphere.rs:36-39
-    const float f = (time - m1.w) / (m2.x - m1.w);
+    const float f = fdiv(time - m1.w, m2.x - m1.w);
     return v3(m0.x + f * (m1.x - m0.x), m0.y + f * (m1.y - m0.y), m0.z + f * (m1.z - m0.z));
 }
 // XyRect/XzRect/YzRect::hit (aarect.rs:31-48, 81-98, 150-167)
 DEVI bool rect_hit(V3 o, V3 d, Float4 r0, Float4 r1, float tmin, float tmax, float& t, float& ha, float& hb) {
     const int kaxis = (int)r1.y;
     const int ia = kaxis == 0 ? 1 : 0, ib = kaxis == 2 ? 1 : 2;
-    const float tt = (r1.x - comp(o, kaxis)) / comp(d, kaxis);
+    const float tt = fdiv(r1.x - comp(o, kaxis), comp(d, kaxis));
     if (tt < tmin || tt > tmax) return false;
     if (!(fabsf(tt) < kInf)) return false;   // never accept t = inf / NaN (ray parallel to the plane)
     const float a = comp(o, ia) + tt * comp(d, ia);
@@ -231,7 +249,7 @@ DEVI bool tri_hit(V3 o, V3 d, V3 v0, V3 v1, V3 v2, float tmin, float tmax, float
     const V3 pv = cross(d, e2);
     const float det = dot(e1, pv);
     if (det == 0.0f) return false;
-    const float inv = 1.0f / det;
+    const float inv = fdiv(1.0f, det);
     const V3 tv = o - v0;
     const float u = dot(tv, pv) * inv;
     if (u < 0.0f || u > 1.0f) return false;
@@ -275,11 +293,11 @@ DEVI bool medium_hit(const SceneDev& sc, const rtd::Medium& m, V3 ow, V3 dw, flo
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
     if (t1 < 0.0f) t1 = 0.0f;
-    const float ray_length = sqrtf(a);
+    const float ray_length = fsqrt(a);
     const float distance_inside_boundary = (t2 - t1) * ray_length;
     const float hit_distance = m.neg_inv_density * logf(xi);
     if (hit_distance > distance_inside_boundary) return false;
-    t = t1 + hit_distance / ray_length;
+    t = t1 + fdiv(hit_distance, ray_length);
     return true;
 }
 
@@ -324,6 +342,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                                                  uint32_t* __restrict__ head, uint32_t* __restrict__ count_out_to_zero,
                                                  unsigned long long* __restrict__ counters, RenderDev rd) {
     extern __shared__ float4 lds[];
+    constexpr uint32_t kStride = LDS ? rtd::NODE_STRIDE_LDS : rtd::NODE_STRIDE_HBM;   // bytes per node record (device_types.h)
     if (blockIdx.x == 0 && threadIdx.x == 0) *count_out_to_zero = 0u;   // the next k_shade appends to it
     const uint32_t count = *count_ptr;
     const uint32_t lane = threadIdx.x & 63u;
@@ -343,7 +362,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         // stage the node records and the sphere records (the whole BVH for book-1-sized scenes): a linear
         // copy, i.e. exactly the shape of LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, LDS
         // address = wave base + lane * 16, no VGPR round trip); all pieces in flight, then one wait + barrier
-        const uint32_t n4 = 2 * (n_nodes + 1u), s4 = sc.n_spheres, tot = n4 + s4;   // nodes (+ closing record) then spheres, contiguous in LDS
+        const uint32_t n4 = (kStride / 16u) * (n_nodes + 1u), s4 = sc.n_spheres, tot = n4 + s4;   // nodes (+ closing record) then spheres, contiguous in LDS
         const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63u, nw = blockDim.x >> 6;
         for (uint32_t base = wave * 64u; base < tot; base += nw * 64u) {
             const uint32_t i = base + ln;
@@ -364,7 +383,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     bool have = false;
     // `node` is the BYTE offset of the lane's next node record; `pend` is 0 while the lane walks, else the leaf word it
     // waits with (or LEAF_IDLE / LEAF_DONE): one compare tells whether the lane takes part in a node step
-    const uint32_t end_off = n_nodes * 32u;
+    const uint32_t end_off = n_nodes * kStride;
     uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE, pend = rtd::LEAF_IDLE, from = 0;
     float tmax = kInf, tm = 0.f, a = 1.f;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
@@ -404,7 +423,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     a = len2(d);
                     if (FEAT & F_XFORM) { ow = o; dw = d; }
                     if (FEAT & F_MEDIUM) {
-                        const uint32_t sd = __float_as_uint(pool.s0[slot].w), xy = pool.s2[slot];
+                        const uint4 q = pool.s3[slot]; const uint32_t sd = q.z, xy = q.w;
                         seg = sd & 0xFFu;
                         mkey = path_base(rd.seed, (uint64_t)(xy >> 16) * rd.width + (xy & 0xFFFFu), sd >> 8);
                     }
@@ -459,7 +478,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             const float tfar = fminf(fminf(fmaxf(t_mn.x, t_mx.x), fmaxf(t_mn.y, t_mx.y)), fminf(fmaxf(t_z.x, t_z.y), tmax));
             const bool boxhit = tnear <= tfar;
             if (COUNT) c_nodes += (walk && n0.x > -kInf) ? 1ull : 0ull;
-            const uint32_t next = boxhit ? node + 32u : skip;
+            const uint32_t next = boxhit ? node + kStride : skip;
             node = walk ? next : node;
             pend = (walk && boxhit) ? leaf : pend;            // leaf == 0 for an inner node
         }
@@ -490,13 +509,25 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             const uint32_t type = pend >> 28, cnt = (pend >> 24) & 15u, first = pend & rtd::LEAF_MAX_FIRST;
             pend = 0u;
             if (type == rtd::LT_SPHERE) {
+                // two phases, so that the f64 refinement (several times the cost of the filter) runs once per SURVIVOR
+                // of the wave's slowest lane, not once per sphere of its largest leaf: first the f32 filter over the
+                // leaf, survivors as a bit mask (count <= 15); then the survivors in leaf order — the order in which
+                // HittableList::hit would shrink t_max
+                uint32_t surv = 0u;
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const float4 s = spheres[first + k];
-                    float t;
                     if (COUNT) c_prims[0]++;
                     const uint32_t id = (rtd::LT_SPHERE << 28) | (first + k);
+                    if (id == from || !sphere_certain_miss(o, d, a, v3(s.x, s.y, s.z), s.w)) surv |= 1u << k;
+                }
+                while (surv != 0u) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(surv);
+                    surv &= surv - 1u;
+                    const float4 s = spheres[first + k];
+                    const uint32_t id = (rtd::LT_SPHERE << 28) | (first + k);
+                    float t;
                     const bool h = (id == from) ? sphere_hit_from_surface(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t)
-                                                : sphere_hit(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t);
+                                                : sphere_roots(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t);
                     if (h) { tmax = t; hit_prim = id; }
                 }
             } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
@@ -618,8 +649,8 @@ DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t s
     g.s = path_base(rd.seed, pixel_index, sample);
     const float ju = g.rnd(), jv = g.rnd();
     const uint32_t j = rd.height - 1u - y;                       // main.rs:733
-    const float u = ((float)x + ju) / (float)(rd.width - 1u);    // main.rs:752
-    const float v = ((float)j + jv) / (float)(rd.height - 1u);   // main.rs:753
+    const float u = fdiv((float)x + ju, (float)(rd.width - 1u));    // main.rs:752
+    const float v = fdiv((float)j + jv, (float)(rd.height - 1u));   // main.rs:753
     // random_in_unit_disk (vec3.rs:101-113): drawn even when lens_radius == 0
     float px, py;
     for (;;) { px = g.range(-1.f, 1.f); py = g.range(-1.f, 1.f); if (px * px + py * py >= 1.0f) continue; break; }
@@ -645,13 +676,14 @@ struct PathState {
     uint32_t from;               // primitive id the ray starts on (hit-record id), 0 = none
     uint64_t rng;
 };
-DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const PathState& s) {
+// 64 bytes per path: ray_o, ray_d, s0 = (T, work item), s3 = (rng, sample << 8 | depth, x | y << 16); the running sum
+// `acc` (s1, +16 bytes) exists only when a work item is more than one sample (with_acc = block_shift != 0).
+DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const PathState& s, bool with_acc) {
     p.ray_o[i] = Float4{o.x, o.y, o.z, tm};
     p.ray_d[i] = Float4{d.x, d.y, d.z, __uint_as_float(s.from)};
-    p.s0[i] = Float4{s.T.x, s.T.y, s.T.z, __uint_as_float(s.sdepth)};
-    p.s1[i] = Float4{s.acc.x, s.acc.y, s.acc.z, __uint_as_float(s.work)};
-    p.s2[i] = s.xy;
-    p.s3[i] = make_uint2((uint32_t)s.rng, (uint32_t)(s.rng >> 32));
+    p.s0[i] = Float4{s.T.x, s.T.y, s.T.z, __uint_as_float(s.work)};
+    p.s3[i] = make_uint4((uint32_t)s.rng, (uint32_t)(s.rng >> 32), s.sdepth, s.xy);
+    if (with_acc) p.s1[i] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
 }
 
 // Workgroup-aggregated allocation: every thread of the block calls it; threads with `flag` get
@@ -692,7 +724,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, Render
     if (got) {
         PathState s; V3 o, d; float tm;
         start_item(rd, work, s, o, d, tm);
-        store_path(pool, dst, o, d, tm, s);
+        store_path(pool, dst, o, d, tm, s, rd.block_shift != 0u);
     }
 }
 
@@ -761,17 +793,17 @@ DEVI float light_pdf_value(const rtd::Light& l, V3 o, V3 v, unsigned long long& 
         const float area = (l.p[1] - l.p[0]) * (l.p[3] - l.p[2]);
         const float distance_squared = t * t * len2(v);
         // rec.normal = +-(0,1,0) against the ray; |dot| makes the sign irrelevant
-        const float cosine = fabsf(v.y / len(v));
-        return distance_squared / cosine / area;
+        const float cosine = fabsf(fdiv(v.y, len(v)));
+        return fdiv(fdiv(distance_squared, cosine), area);
     }
     if (l.kind == rtd::LK_SPHERE) {                                            // sphere.rs:75-84
         tests++;
         const V3 c = v3(l.p[0], l.p[1], l.p[2]); const float r = l.p[3];
         float t;
         if (!sphere_roots(o, v, len2(v), c, r, kTMin, kInf, t)) return 0.f;
-        const float cos_theta_max = sqrtf(1.f - r * r / len2(c - o));
+        const float cos_theta_max = fsqrt(1.f - fdiv(r * r, len2(c - o)));
         const float solid_angle = 2.f * kPi * (1.f - cos_theta_max);
-        return 1.f / solid_angle;
+        return fdiv(1.f, solid_angle);
     }
     return 0.f;                                                                // hittable.rs:54-56
 }
@@ -797,8 +829,8 @@ DEVI V3 light_random(const rtd::Light& l, V3 o, Rng& g) {
 DEVI void sphere_uv(V3 p, float& u, float& v) {                                // sphere.rs:32-37
     const float theta = acosf(-p.y);
     const float phi = atan2f(-p.z, p.x) + kPi;
-    u = phi / (2.f * kPi);
-    v = theta / kPi;
+    u = phi * (0.5f * kInvPi);
+    v = theta * kInvPi;
 }
 
 template <uint32_t FEAT, bool COUNT>
@@ -814,15 +846,16 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
         if (count_in) atomicAdd(&counters[CTR_ITERATIONS], 1ull);
     }
     bool alive = i < count_in;
+    const bool with_acc = rd.block_shift != 0u;
     PathState s{}; V3 o = v3(0, 0, 0), d = v3(0, 0, 1); float tm = 0.f;
     unsigned long long c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
     bool want_work = false;
     if (alive) {
-        const Float4 ro = in.ray_o[i], rdv = in.ray_d[i], s0 = in.s0[i], s1 = in.s1[i];
-        const uint2 s3 = in.s3[i], hit = in.hit[i];
+        const Float4 ro = in.ray_o[i], rdv = in.ray_d[i], s0 = in.s0[i];
+        const uint4 s3 = in.s3[i]; const uint2 hit = in.hit[i];
         o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
-        s.T = v3(s0.x, s0.y, s0.z); s.sdepth = __float_as_uint(s0.w);
-        s.acc = v3(s1.x, s1.y, s1.z); s.work = __float_as_uint(s1.w); s.xy = in.s2[i];
+        s.T = v3(s0.x, s0.y, s0.z); s.work = __float_as_uint(s0.w); s.sdepth = s3.z; s.xy = s3.w;
+        if (with_acc) { const Float4 s1 = in.s1[i]; s.acc = v3(s1.x, s1.y, s1.z); }   // else 0: the item is this one sample
         V3 L = v3(0.f, 0.f, 0.f);          // radiance of this sample: set by the terminal event only
         s.rng = (uint64_t)s3.x | ((uint64_t)s3.y << 32);
         Rng g; g.s = s.rng;
@@ -870,7 +903,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
                     const int kaxis = (int)r1.y; const int ia = kaxis == 0 ? 1 : 0, ib = kaxis == 2 ? 1 : 2;
                     p = ol + dl * t;                                            // aarect.rs:46
                     const float a = comp(p, ia), b = comp(p, ib);
-                    hu = (a - r0.x) / (r0.y - r0.x); hv = (b - r0.z) / (r0.w - r0.z);   // :41-42
+                    hu = fdiv(a - r0.x, r0.y - r0.x); hv = fdiv(b - r0.z, r0.w - r0.z);   // :41-42
                     // on the plane exactly: the f64 reference's r.at(t) lands within 1e-13 of k
                     if (kaxis == 0) p.x = r1.x; else if (kaxis == 1) p.y = r1.x; else p.z = r1.x;
                     outward = v3(kaxis == 0 ? 1.f : 0.f, kaxis == 1 ? 1.f : 0.f, kaxis == 2 ? 1.f : 0.f);
@@ -950,16 +983,16 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
                             lsum += weight * light_pdf_value(l, p, dir, l.kind == rtd::LK_XZRECT ? c_light_rect : c_light_sphere);
                         }
                         const float cosine = dot(unit(dir), uvw.w);
-                        const float cpdf = cosine <= 0.f ? 0.f : cosine / kPi;   // pdf.rs:24-31
+                        const float cpdf = cosine <= 0.f ? 0.f : cosine * kInvPi;   // pdf.rs:24-31
                         pdf_val = 0.5f * lsum + 0.5f * cpdf;
                     } else {
                         dir = onb_local(uvw, random_cosine_direction(g));       // pdf.rs:32-34
                         const float cosine = dot(unit(dir), uvw.w);
-                        pdf_val = cosine <= 0.f ? 0.f : cosine / kPi;
+                        pdf_val = cosine <= 0.f ? 0.f : cosine * kInvPi;
                     }
                     const float cosine_s = dot(n, unit(dir));                   // scattering_pdf, material.rs:64-71
-                    const float spdf = cosine_s < 0.f ? 0.f : cosine_s / kPi;
-                    s.T = s.T * colour * spdf / pdf_val;                        // main.rs:130-138 (emitted = 0)
+                    const float spdf = cosine_s < 0.f ? 0.f : cosine_s * kInvPi;
+                    s.T = s.T * colour * fdiv(spdf, pdf_val);                   // main.rs:130-138 (emitted = 0)
                     o = p; d = dir;                                             // main.rs:96 (time kept)
                 } else if (kind == rtd::MK_METAL) {
                     // Metal::scatter (material.rs:96-107): the fuzz sphere is drawn even for fuzz 0; time := 0.0
@@ -970,14 +1003,14 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
                 } else if (kind == rtd::MK_DIELECTRIC) {
                     // Dielectric::scatter (material.rs:131-155)
                     const float ir = ma.w;
-                    const float ratio = ff ? 1.0f / ir : ir;
+                    const float ratio = ff ? fdiv(1.0f, ir) : ir;
                     const V3 ud = unit(d);
                     const float cos_theta = fminf(dot(-ud, n), 1.0f);
-                    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                    const float sin_theta = fsqrt(1.0f - cos_theta * cos_theta);
                     const bool cannot_refract = ratio * sin_theta > 1.0f;
                     bool refl = cannot_refract;
                     if (!refl) {                                                // `||` short-circuit: draw only if it can refract
-                        float r0 = (1.f - ratio) / (1.f + ratio); r0 *= r0;
+                        float r0 = fdiv(1.f - ratio, 1.f + ratio); r0 *= r0;
                         const float m = 1.f - cos_theta;
                         const float reflectance = r0 + (1.f - r0) * (m * m * m * m * m);   // material.rs:123-127
                         refl = reflectance > g.rnd();
@@ -1026,7 +1059,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     // ---- compaction: survivors go to the other pool densely (wave64 ballot + prefix, LDS scan across waves) ----
     {
         const uint32_t dst = block_alloc(alive, count_out, s_scan);
-        if (alive) store_path(out, dst, o, d, tm, s);
+        if (alive) store_path(out, dst, o, d, tm, s, with_acc);
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { c_samples += __shfl_down(c_samples, off); c_light_rect += __shfl_down(c_light_rect, off); c_light_sphere += __shfl_down(c_light_sphere, off); }
@@ -1083,7 +1116,7 @@ __global__ void __launch_bounds__(256) k_write_color(const float* __restrict__ r
 template <bool LDS, uint32_t FEAT, bool COUNT>
 static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
-    const size_t lds_bytes = LDS ? (((size_t)sc.n_nodes + 1u) * 32u + (size_t)sc.n_spheres * 16u) : 0u;
+    const size_t lds_bytes = LDS ? (((size_t)sc.n_nodes + 1u) * rtd::NODE_STRIDE_LDS + (size_t)sc.n_spheres * 16u) : 0u;
     static thread_local size_t cached_lds = ~(size_t)0; static thread_local int nb_small = 0, nb_big = 0;
     if (cached_lds != lds_bytes) {
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_small, k_extend<LDS, FEAT, COUNT, kExtendThreads>, (int)kExtendThreads, lds_bytes);

@@ -43,7 +43,7 @@ struct RtCtx {
     int n_cu = 256;
     std::string err;
     // grow-only work buffers
-    DevBuf pool[2][7]; DevBuf blocksum; DevBuf counters; DevBuf out_tmp; DevBuf tile_prefix;
+    DevBuf pool[2][6]; DevBuf blocksum; DevBuf counters; DevBuf out_tmp; DevBuf tile_prefix;
     uint32_t* h_count = nullptr;                 // pinned
     unsigned long long* h_counters = nullptr;    // pinned
     std::vector<hipEvent_t> events;
@@ -143,17 +143,20 @@ int rt_ctx_destroy(RtCtx* ctx) {
     return RT_OK;
 }
 
-// device layout of the threaded BVH (device_types.h: NodeDev) + the closing record
-static std::vector<rtd::NodeDev> device_nodes(const std::vector<rtd::Node>& nodes) {
-    std::vector<rtd::NodeDev> out(nodes.size() + 1);
+// device layout of the threaded BVH (device_types.h: NodeDev) + the closing record, `stride` bytes per record
+static std::vector<unsigned char> device_nodes(const std::vector<rtd::Node>& nodes, uint32_t stride) {
+    std::vector<unsigned char> out((nodes.size() + 1) * (size_t)stride, 0);
     for (size_t i = 0; i < nodes.size(); ++i) {
         const rtd::Node& n = nodes[i];
-        out[i] = rtd::NodeDev{n.mn[0], n.mn[1], n.mx[0], n.mx[1], n.mn[2], n.mx[2], n.skip * 32u, n.leaf};
+        const rtd::NodeDev d{n.mn[0], n.mn[1], n.mx[0], n.mx[1], n.mn[2], n.mx[2], n.skip * stride, n.leaf};
+        std::memcpy(out.data() + i * stride, &d, sizeof(d));
     }
     const float inf = std::numeric_limits<float>::infinity();
-    out[nodes.size()] = rtd::NodeDev{-inf, -inf, inf, inf, -inf, inf, (uint32_t)nodes.size() * 32u, rtd::LEAF_DONE};
+    const rtd::NodeDev end{-inf, -inf, inf, inf, -inf, inf, (uint32_t)nodes.size() * stride, rtd::LEAF_DONE};
+    std::memcpy(out.data() + nodes.size() * stride, &end, sizeof(end));
     return out;
 }
+static size_t lds_scene_bytes(const rtc::CompiledScene& cs) { return (cs.nodes.size() + 1) * (size_t)rtd::NODE_STRIDE_LDS + cs.spheres.size() * 16; }
 
 int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
@@ -166,7 +169,8 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     RtScene* s = new RtScene();
     int r = RT_OK;
     auto up = [&](auto& buf, const auto& vec) { if (r == RT_OK) r = upload(ctx, buf, vec); };
-    const std::vector<rtd::NodeDev> dnodes = device_nodes(cs.nodes);   // alive until the stream sync below
+    const bool in_lds = lds_scene_bytes(cs) <= kLdsSceneBudget;
+    const std::vector<unsigned char> dnodes = device_nodes(cs.nodes, in_lds ? rtd::NODE_STRIDE_LDS : rtd::NODE_STRIDE_HBM);   // alive until the stream sync below
     up(s->nodes, dnodes); up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
     up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->media, cs.media);
     up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
@@ -186,8 +190,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     d.lights = (const rtd::Light*)s->lights.p; d.n_lights = (uint32_t)cs.lights.size();
     const uint32_t f = scene_features(cs);
     s->features = f;
-    const size_t lds_bytes = (cs.nodes.size() + 1) * 32 + cs.spheres.size() * 16;
-    s->in_lds = lds_bytes <= kLdsSceneBudget; s->lds_bytes = lds_bytes;
+    s->in_lds = in_lds; s->lds_bytes = lds_scene_bytes(cs);
     s->bg_mode = cs.background_mode; for (int i = 0; i < 3; ++i) s->bg[i] = cs.background[i];
     s->n_nodes = cs.nodes.size();
     s->n_prims = cs.sphere_meta.size() + cs.moving_meta.size() + cs.rect_meta.size() + cs.tri_meta.size() + cs.media.size();
@@ -241,7 +244,8 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     // 2^30 samples — a path is then one sample, nothing is regenerated mid-flight and the radiance of every sample
     // is stored on its own (16 GB of block sums at the limit; this is a 288 GB device). Larger renders group 2, 4, ...
     // consecutive samples of a pixel into one item.
-    uint32_t block_shift = 0;
+    uint32_t block_shift = (prm->flags & RT_FLAG_SAMPLE_BLOCKS) ? 4u : 0u;
+    while ((1u << block_shift) > rd.spp && block_shift > 0) --block_shift;
     {
         const uint64_t image_pixels = (uint64_t)prm->width * prm->height;
         while ((1u << block_shift) < rd.spp && image_pixels * ((rd.spp + (1u << block_shift) - 1) >> block_shift) > (1ull << 30)) ++block_shift;
@@ -258,14 +262,14 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
 
     // Pool: as many paths in flight as there are work items, up to 2^28 (45 GB for the two pools) and to what the
     // device has free. Launches then carry hundreds of millions of rays: few launches, short tails.
-    static const size_t rec[7] = {16, 16, 8, 16, 16, 4, 8};
-    size_t slot_bytes = 0; for (int a = 0; a < 7; ++a) slot_bytes += 2 * rec[a];
+    const size_t rec[6] = {16, 16, 8, 16, 16, block_shift ? (size_t)16 : (size_t)0};   // ray_o ray_d hit s0 s3 [s1 = acc]
+    size_t slot_bytes = 0; for (int a = 0; a < 6; ++a) slot_bytes += 2 * rec[a];
     uint32_t P = prm->pool_slots ? prm->pool_slots : (1u << 28);
     P = (uint32_t)std::min<uint64_t>(P, total_items);
     if (!prm->pool_slots) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            size_t held = ctx->blocksum.bytes; for (int k = 0; k < 2; ++k) for (int a = 0; a < 7; ++a) held += ctx->pool[k][a].bytes;
+            size_t held = ctx->blocksum.bytes; for (int k = 0; k < 2; ++k) for (int a = 0; a < 6; ++a) held += ctx->pool[k][a].bytes;
             const size_t avail = free_b + held, need_sum = (size_t)total_items * 16;
             const size_t budget = avail * 7 / 10 > need_sum ? avail * 7 / 10 - need_sum : 0;
             while (P > (1u << 20) && (size_t)P * slot_bytes > budget) P >>= 1;
@@ -274,10 +278,9 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     P = std::max<uint32_t>(256u, (P + 255u) & ~255u);
     rtk::PoolDev pd[2];
     for (int k = 0; k < 2; ++k) {
-        for (int a = 0; a < 7; ++a) HIP_TRY(ctx, ctx->pool[k][a].ensure((size_t)P * rec[a]));
+        for (int a = 0; a < 6; ++a) if (rec[a]) HIP_TRY(ctx, ctx->pool[k][a].ensure((size_t)P * rec[a]));
         pd[k].ray_o = (rtd::Float4*)ctx->pool[k][0].p; pd[k].ray_d = (rtd::Float4*)ctx->pool[k][1].p; pd[k].hit = (uint2*)ctx->pool[k][2].p;
-        pd[k].s0 = (rtd::Float4*)ctx->pool[k][3].p; pd[k].s1 = (rtd::Float4*)ctx->pool[k][4].p; pd[k].s2 = (uint32_t*)ctx->pool[k][5].p;
-        pd[k].s3 = (uint2*)ctx->pool[k][6].p;
+        pd[k].s0 = (rtd::Float4*)ctx->pool[k][3].p; pd[k].s3 = (uint4*)ctx->pool[k][4].p; pd[k].s1 = rec[5] ? (rtd::Float4*)ctx->pool[k][5].p : nullptr;
     }
     HIP_TRY(ctx, ctx->blocksum.ensure((size_t)total_items * 16));
     rd.blocksum = (rtd::Float4*)ctx->blocksum.p;
@@ -434,7 +437,7 @@ int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out) {
     out->n_rects = cs.rect_meta.size(); out->n_tris = cs.tri_meta.size(); out->n_media = cs.media.size(); out->n_xforms = cs.xforms.size();
     out->n_lights = cs.lights.size(); out->n_materials = cs.mat_b.size();
     out->features = scene_features(cs);
-    out->fits_lds = ((cs.nodes.size() + 1) * 32 + cs.spheres.size() * 16) <= kLdsSceneBudget ? 1u : 0u;
+    out->fits_lds = lds_scene_bytes(cs) <= kLdsSceneBudget ? 1u : 0u;
     return RT_OK;
 }
 

@@ -20,4 +20,5 @@ for r in range(reps):
     t = time.time()
     img, st = ctx.render(scene, cam, p.make_params(W, H, spp, flags=flags))
     dt = time.time() - t
-    print(name, W, H, spp, "%.1f ms" % (dt * 1e3), "%.1f Msamples/s" % (W * H * spp / dt / 1e6), "segments", st["segments"], "iters", st["iterations"], "geom", st["debug"][6:8], flush=True)
+    print(name, W, H, spp, "%.1f ms" % (dt * 1e3), "%.1f Msamples/s" % (W * H * spp / dt / 1e6), "segments", st["segments"], "iters", st["iterations"], "geom", st["debug"][6:8],
+          "extend %.1f shade %.1f other %.1f ms" % (st["extend_ms"], st["shade_ms"], st["other_ms"]), flush=True)

@@ -6,7 +6,7 @@ def short(n):
             return k + ("<count>" if ", true>" in n else "")
     return n[:40]
 for d in sys.argv[1:]:
-    for f in glob.glob(d + "/*/*counter_collection.csv"):
+    for f in glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"):
         acc = collections.defaultdict(lambda: collections.defaultdict(float))
         nd = collections.defaultdict(set)
         for r in csv.DictReader(open(f)):

@@ -27,6 +27,7 @@ VARIANTS = {
     "bs2": ["RT_BLOCK_SHIFT=2"],
     "bs3": ["RT_BLOCK_SHIFT=3"],
     "bs5": ["RT_BLOCK_SHIFT=5"],
+    "st32": ["RT_NODE_STRIDE_LDS=32"],
     "o5": ["RT_EXTEND_PER_CU_MAX=5"],
     "o4": ["RT_EXTEND_PER_CU_MAX=4"],
     "o3": ["RT_EXTEND_PER_CU_MAX=3"],
@@ -43,7 +44,7 @@ if sys.argv[1] == "build":
             print(n, p)
 else:
     names = sys.argv[2:] or list(VARIANTS)
-    pools = [int(x) for x in os.environ.get("POOLS", "16777216").split(",")]
+    pools = [int(x) for x in os.environ.get("POOLS", "0").split(",")]
     for n in names:
         for pool in pools:
             env = dict(os.environ, RT_HIP_LIB=os.path.join(ROOT, "ray-tracer-archive_amd", "lib", "variants", f"librt_hip_{n}.so"))

@@ -82,6 +82,13 @@ def test_bit_exact_invariances(pkg, gpu, book1):
         assert np.array_equal(D.assemble(base, np.stack(parts), world), a)
     f, _ = gpu.render(scene, cam, pkg.make_params(W, H, SPP, seed=6))
     assert not np.array_equal(a, f)
+    # work items of 16 samples (the layout of images above 2^30 samples; paths are regenerated in flight and carry a
+    # running sum): the same samples, summed block-wise, so equal to rounding; bit-stable against the pool size too
+    SB = pkg._abi.RT_FLAG_SAMPLE_BLOCKS
+    g16, _ = gpu.render(scene, cam, pkg.make_params(W, H, SPP, seed=5, flags=SB))
+    h16, st = gpu.render(scene, cam, pkg.make_params(W, H, SPP, seed=5, flags=SB, pool_slots=2048))
+    assert st["pool_slots"] == 2048 and np.array_equal(g16, h16)
+    assert np.allclose(g16, a, rtol=1e-5, atol=1e-5) and st["samples"] == W * H * SPP
 
 
 def test_list_and_bvh_give_the_same_picture(pkg, gpu):
