@@ -38,11 +38,12 @@ inline uint32_t make_leaf(uint32_t type, uint32_t first, uint32_t count) { retur
 // node is not counted as an Aabb::hit.
 //
 // The DEVICE copy of the array (rt_api.cpp: device_nodes) holds the same records regrouped for the
-// kernel: a = (mn.x, mn.y, mx.x, mx.y), b = (mn.z, mx.z, skip * 32, leaf) — one visit is then three
-// packed FMAs (v_pk_fma_f32) and `skip` is already the byte offset of the next record. One extra
-// record closes the array (index n_nodes): no box, skip to itself, leaf = LEAF_DONE, so a lane that has
-// walked off the end parks there and k_extend's node step needs no bounds test.
-struct NodeDev { float mnx, mny, mxx, mxy, mnz, mxz; uint32_t skip_bytes, leaf; };
+// kernel, boxes as centre c and half extent h: a = (c.x, c.y, h.x, h.y), b = (c.z, h.z, skip * stride, leaf).
+// A ray meets an axis' slab at tc -+ th (tc = c/d - o/d, th = h/|d|): no min/max to order the planes, and
+// one visit is two packed FMAs, a packed multiply and two packed adds; `skip` is already the byte offset
+// of the next record. h is rounded up and padded so that [c-h, c+h] contains the (padded) host box; a
+// record without a box has c = 0, h = inf. One extra
+struct NodeDev { float cx, cy, hx, hy, cz, hz; uint32_t skip_bytes, leaf; };
 static_assert(sizeof(NodeDev) == 32, "device node record is 32 bytes");
 // Record stride. In HBM records are packed. A scene that k_extend keeps in LDS is laid out with 48-byte
 // records (16 bytes of padding): the two 16-byte halves of 32-byte records only ever land on 8 of the 16

@@ -305,26 +305,36 @@ DEVI bool medium_hit(const SceneDev& sc, const rtd::Medium& m, V3 ow, V3 dw, flo
 // k_extend — world.hit for the whole pool
 // ------------------------------------------------------------------------------------------------
 typedef float F2 __attribute__((ext_vector_type(2)));
-// per-ray constants of the slab test t = n * (1/d) - o/d. Culling only: boxes carry the slack (scene_compile.cpp)
-DEVI void set_slab_ray(V3 o, V3 d, F2& inv_xy, F2& inv_zz, F2& noi_xy, F2& noi_zz) {
-    const V3 inv = v3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
-    inv_xy = F2{inv.x, inv.y}; inv_zz = F2{inv.z, inv.z};
-    noi_xy = F2{-(o.x * inv.x), -(o.y * inv.y)}; noi_zz = F2{-(o.z * inv.z), -(o.z * inv.z)};
+// per-ray constants of the slab test. Boxes are stored as centre c and half extent h (device_types.h: NodeDev): the ray
+// meets the slab of one axis at tc -+ th with tc = c/d - o/d and th = h/|d|, which needs no min/max to order the two
+// planes. Culling only: boxes carry the rounding slack (scene_compile.cpp pad + rt_api.cpp device_nodes).
+struct SlabRay { F2 inv_xy, noi_xy, ainv_xy, inv_z, noi_z; };   // inv_z = (1/d.z, |1/d.z|), noi_z = (-o.z/d.z, 0)
+DEVI void set_slab_ray(V3 o, V3 d, SlabRay& r) {
+    // A direction component of exactly 0 (a cosine-sampled bounce with r2 = 0 leaves the surface along its normal: one ray
+    // in 2^24) would make 1/d infinite, c/d - o/d = inf - inf, and the ray would pass EVERY box: 1.5 M dependent visits in
+    // one lane stall a whole launch for most of a second. |1/d| is capped at 1e18 instead: such a ray is parallel to the
+    // slab for every t the scene can hold, and inside/outside is still decided by the sign of c - o -+ h.
+    const float kInvMax = 1e18f;
+    const V3 inv = v3(fminf(fmaxf(fast_rcp(d.x), -kInvMax), kInvMax), fminf(fmaxf(fast_rcp(d.y), -kInvMax), kInvMax),
+                      fminf(fmaxf(fast_rcp(d.z), -kInvMax), kInvMax));
+    r.inv_xy = F2{inv.x, inv.y}; r.ainv_xy = F2{fabsf(inv.x), fabsf(inv.y)};
+    r.noi_xy = F2{-(o.x * inv.x), -(o.y * inv.y)};
+    r.inv_z = F2{inv.z, fabsf(inv.z)}; r.noi_z = F2{-(o.z * inv.z), 0.f};
 }
 #ifndef RT_CHUNK
-#define RT_CHUNK 256        // rays a wave takes from the queue head per atomic
+#define RT_CHUNK 1024       // rays a wave takes from the queue head per atomic (2^28 rays per launch: same-address atomics cost ~11 ns each)
 #endif
 #ifndef RT_STEPS
 #define RT_STEPS 4          // node visits between two looks at the leaf batch / the refill
 #endif
 #ifndef RT_LEAF_BATCH
-#define RT_LEAF_BATCH 16    // lanes with a pending leaf that trigger a primitive-test pass
+#define RT_LEAF_BATCH 24    // lanes with a pending leaf that trigger a primitive-test pass
 #endif
 #ifndef RT_EXTEND_THREADS
 #define RT_EXTEND_THREADS 256   // workgroup of k_extend: all its waves share one LDS copy of the scene
 #endif
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 16    // idle lanes that trigger a refill (the refill pass runs with only those lanes active)
+#define RT_REFILL_MIN 24    // idle lanes that trigger a refill (the refill pass runs with only those lanes active)
 #endif
 constexpr int kRefillMin = RT_REFILL_MIN;
 constexpr uint32_t kExtendThreads = RT_EXTEND_THREADS;
@@ -362,7 +372,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         // stage the node records and the sphere records (the whole BVH for book-1-sized scenes): a linear
         // copy, i.e. exactly the shape of LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, LDS
         // address = wave base + lane * 16, no VGPR round trip); all pieces in flight, then one wait + barrier
-        const uint32_t n4 = (kStride / 16u) * (n_nodes + 1u), s4 = sc.n_spheres, tot = n4 + s4;   // nodes (+ closing record) then spheres, contiguous in LDS
+        const uint32_t n4 = (kStride / 16u) * (n_nodes + 2u), s4 = sc.n_spheres, tot = n4 + s4;   // nodes (+ closing record + pad) then spheres, contiguous in LDS
         const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63u, nw = blockDim.x >> 6;
         for (uint32_t base = wave * 64u; base < tot; base += nw * 64u) {
             const uint32_t i = base + ln;
@@ -387,10 +397,13 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE, pend = rtd::LEAF_IDLE, from = 0;
     float tmax = kInf, tm = 0.f, a = 1.f;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
-    F2 inv_xy = {0.f, 0.f}, inv_zz = {0.f, 0.f}, noi_xy = {0.f, 0.f}, noi_zz = {0.f, 0.f};   // 1/d and -o/d, paired for v_pk_fma_f32
+    SlabRay sr; sr.inv_xy = sr.noi_xy = sr.ainv_xy = sr.inv_z = sr.noi_z = F2{0.f, 0.f};
     V3 ow = o, dw = d;                 // world ray while inside an instance transform
     uint64_t mkey = 0; uint32_t seg = 0;
     unsigned long long c_nodes = 0, c_prims[RT_N_PRIM_TYPES_K] = {0, 0, 0, 0, 0, 0};
+#ifdef RT_DEBUG_LONGWALK
+    uint32_t dbg_steps = 0u;
+#endif
 
 #ifdef RT_STAMPS
     unsigned long long st_refill = 0, st_node = 0, st_prim = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
@@ -419,7 +432,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     slot = w_next + rank;
                     o = v3(ox, oy, oz); d = v3(dx, dy, dz); tm = ot;
                     from = __float_as_uint(dfrom);            // primitive this ray starts on (0: camera / medium)
-                    set_slab_ray(o, d, inv_xy, inv_zz, noi_xy, noi_zz);
+                    set_slab_ray(o, d, sr);
                     a = len2(d);
                     if (FEAT & F_XFORM) { ow = o; dw = d; }
                     if (FEAT & F_MEDIUM) {
@@ -465,19 +478,38 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #pragma unroll
         for (int step = 0; step < kSteps; ++step) {
             const bool walk = pend == 0u;
+#ifdef RT_PARK_READS_ROOT
             const uint32_t off = walk ? node : 0u;
-            const float4 n0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off);
-            const float4 n1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off + 16u);
+#else
+            const uint32_t off = node;      // a parked lane re-reads its own next record (an idle one record 0) and ignores it
+#endif
+            float4 n0, n1;
+            if constexpr (LDS) {
+                // k_extend has no static LDS, so the staged copy starts at LDS address 0: the record's offset IS its address
+                // (saves the add of a link-time base per visit; the staging loop above writes through `lds`, the same bytes)
+                typedef float F4V __attribute__((ext_vector_type(4)));
+                typedef const __attribute__((address_space(3))) F4V* lds_f4;
+                const F4V a0 = *reinterpret_cast<lds_f4>(off), a1 = *reinterpret_cast<lds_f4>(off + 16u);
+                n0 = make_float4(a0.x, a0.y, a0.z, a0.w); n1 = make_float4(a1.x, a1.y, a1.z, a1.w);
+            } else {
+                n0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off);
+                n1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off + 16u);
+            }
             const uint32_t skip = __float_as_uint(n1.z), leaf = __float_as_uint(n1.w);
-            // Aabb::hit (aabb.rs:31-55, interval carried across axes). min/max ignore a NaN
-            // operand (0*inf), which keeps the box — conservative, like the reference.
-            const F2 t_mn = __builtin_elementwise_fma(F2{n0.x, n0.y}, inv_xy, noi_xy);   // (tx0, ty0)
-            const F2 t_mx = __builtin_elementwise_fma(F2{n0.z, n0.w}, inv_xy, noi_xy);   // (tx1, ty1)
-            const F2 t_z = __builtin_elementwise_fma(F2{n1.x, n1.y}, inv_zz, noi_zz);    // (tz0, tz1)
-            const float tnear = fmaxf(fmaxf(fminf(t_mn.x, t_mx.x), fminf(t_mn.y, t_mx.y)), fmaxf(fminf(t_z.x, t_z.y), kTMin));
-            const float tfar = fminf(fminf(fmaxf(t_mn.x, t_mx.x), fmaxf(t_mn.y, t_mx.y)), fminf(fmaxf(t_z.x, t_z.y), tmax));
+            // Aabb::hit (aabb.rs:31-55, interval carried across axes), on (centre, half extent): 4 packed ops for x and y,
+            // one packed FMA + add/sub for z. min3/max3 ignore a NaN operand (0*inf), which keeps the box — conservative,
+            // like the reference. A record without a box has h = inf.
+            const F2 tc = __builtin_elementwise_fma(F2{n0.x, n0.y}, sr.inv_xy, sr.noi_xy);   // (tcx, tcy)
+            const F2 th = F2{n0.z, n0.w} * sr.ainv_xy;                                         // (thx, thy)
+            const F2 tz = __builtin_elementwise_fma(F2{n1.x, n1.y}, sr.inv_z, sr.noi_z);      // (tcz, thz)
+            const F2 lo = tc - th, hi = tc + th;
+            const float tnear = fmaxf(fmaxf(lo.x, lo.y), fmaxf(tz.x - tz.y, kTMin));
+            const float tfar = fminf(fminf(hi.x, hi.y), fminf(tz.x + tz.y, tmax));
             const bool boxhit = tnear <= tfar;
-            if (COUNT) c_nodes += (walk && n0.x > -kInf) ? 1ull : 0ull;
+            if (COUNT) c_nodes += (walk && n0.z < kInf) ? 1ull : 0ull;
+#ifdef RT_DEBUG_LONGWALK
+            if (COUNT) dbg_steps += walk ? 1u : 0u;
+#endif
             const uint32_t next = boxhit ? node + kStride : skip;
             node = walk ? next : node;
             pend = (walk && boxhit) ? leaf : pend;            // leaf == 0 for an inner node
@@ -485,7 +517,17 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         // ---- rare events, outside the steps ----
         if (pend == rtd::LEAF_DONE || (pend == 0u && node >= end_off)) {   // walked off the end: world.hit is done
             pool.hit[slot] = make_uint2(__float_as_uint(tmax), hit_prim);
-            have = false; pend = rtd::LEAF_IDLE;
+#ifdef RT_DEBUG_LONGWALK
+            if (COUNT && dbg_steps > 100000u) {
+                atomicAdd(&counters[CTR_DEBUG + 0], 1ull);
+                counters[CTR_DEBUG + 1] = ((unsigned long long)__float_as_uint(o.x) << 32) | __float_as_uint(o.y);
+                counters[CTR_DEBUG + 2] = ((unsigned long long)__float_as_uint(o.z) << 32) | __float_as_uint(d.x);
+                counters[CTR_DEBUG + 3] = ((unsigned long long)__float_as_uint(d.y) << 32) | __float_as_uint(d.z);
+                counters[CTR_DEBUG + 4] = ((unsigned long long)__float_as_uint(tmax) << 32) | from;
+            }
+            dbg_steps = 0u;
+#endif
+            have = false; pend = rtd::LEAF_IDLE; node = 0u;
         }
         if (FEAT & F_XFORM) {
             const uint32_t type = pend >> 28;
@@ -493,7 +535,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                 const uint32_t xf = pend & rtd::LEAF_MAX_FIRST;
                 if (xf == 0u) { o = ow; d = dw; }
                 else xform_ray(sc.xforms[xf], ow, dw, o, d);
-                set_slab_ray(o, d, inv_xy, inv_zz, noi_xy, noi_zz);
+                set_slab_ray(o, d, sr);
                 if (COUNT) { if (type == rtd::LT_ENTER) c_prims[5]++; }
                 pend = 0u;
             }
@@ -1116,7 +1158,7 @@ __global__ void __launch_bounds__(256) k_write_color(const float* __restrict__ r
 template <bool LDS, uint32_t FEAT, bool COUNT>
 static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
-    const size_t lds_bytes = LDS ? (((size_t)sc.n_nodes + 1u) * rtd::NODE_STRIDE_LDS + (size_t)sc.n_spheres * 16u) : 0u;
+    const size_t lds_bytes = LDS ? (((size_t)sc.n_nodes + 2u) * rtd::NODE_STRIDE_LDS + (size_t)sc.n_spheres * 16u) : 0u;
     static thread_local size_t cached_lds = ~(size_t)0; static thread_local int nb_small = 0, nb_big = 0;
     if (cached_lds != lds_bytes) {
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_small, k_extend<LDS, FEAT, COUNT, kExtendThreads>, (int)kExtendThreads, lds_bytes);

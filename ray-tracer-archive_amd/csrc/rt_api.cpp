@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -145,18 +146,36 @@ int rt_ctx_destroy(RtCtx* ctx) {
 
 // device layout of the threaded BVH (device_types.h: NodeDev) + the closing record, `stride` bytes per record
 static std::vector<unsigned char> device_nodes(const std::vector<rtd::Node>& nodes, uint32_t stride) {
-    std::vector<unsigned char> out((nodes.size() + 1) * (size_t)stride, 0);
+    std::vector<unsigned char> out((nodes.size() + 2) * (size_t)stride, 0);   // + closing record + one record of padding
+    const float inf = std::numeric_limits<float>::infinity();
+    double extent = 0.0;
+    for (const rtd::Node& n : nodes) for (int a = 0; a < 3; ++a) {
+        if (std::isfinite(n.mn[a])) extent = std::max(extent, (double)std::fabs(n.mn[a]));
+        if (std::isfinite(n.mx[a])) extent = std::max(extent, (double)std::fabs(n.mx[a]));
+    }
     for (size_t i = 0; i < nodes.size(); ++i) {
         const rtd::Node& n = nodes[i];
-        const rtd::NodeDev d{n.mn[0], n.mn[1], n.mx[0], n.mx[1], n.mn[2], n.mx[2], n.skip * stride, n.leaf};
+        float c[3], h[3];
+        for (int a = 0; a < 3; ++a) {
+            if (!std::isfinite(n.mn[a]) || !std::isfinite(n.mx[a])) { c[a] = 0.f; h[a] = inf; continue; }
+            c[a] = (float)(0.5 * ((double)n.mn[a] + (double)n.mx[a]));
+            // half extent that covers both planes from the ROUNDED centre, plus the slack of the device's three
+            // roundings (tc, th, tc -+ th; ~3e-7 * (|c| + |o|) in space, |o| <= extent like scene_compile.cpp assumes)
+            double hd = std::max((double)n.mx[a] - (double)c[a], (double)c[a] - (double)n.mn[a]);
+            hd = hd * (1.0 + 1e-6) + 5e-7 * (std::fabs((double)c[a]) + extent);
+            float hf = (float)hd; if ((double)hf < hd) hf = std::nextafterf(hf, inf);
+            h[a] = hf;
+        }
+        const rtd::NodeDev d{c[0], c[1], h[0], h[1], c[2], h[2], n.skip * stride, n.leaf};
         std::memcpy(out.data() + i * stride, &d, sizeof(d));
     }
-    const float inf = std::numeric_limits<float>::infinity();
-    const rtd::NodeDev end{-inf, -inf, inf, inf, -inf, inf, (uint32_t)nodes.size() * stride, rtd::LEAF_DONE};
+    const rtd::NodeDev end{0.f, 0.f, inf, inf, 0.f, inf, (uint32_t)nodes.size() * stride, rtd::LEAF_DONE};
     std::memcpy(out.data() + nodes.size() * stride, &end, sizeof(end));
+    // the lane that "hits" the closing record parks with its offset one record further and keeps reading there: a second copy
+    std::memcpy(out.data() + (nodes.size() + 1) * stride, &end, sizeof(end));
     return out;
 }
-static size_t lds_scene_bytes(const rtc::CompiledScene& cs) { return (cs.nodes.size() + 1) * (size_t)rtd::NODE_STRIDE_LDS + cs.spheres.size() * 16; }
+static size_t lds_scene_bytes(const rtc::CompiledScene& cs) { return (cs.nodes.size() + 2) * (size_t)rtd::NODE_STRIDE_LDS + cs.spheres.size() * 16; }
 
 int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");

@@ -15,7 +15,16 @@ VARIANTS = {
     "t512": ["RT_EXTEND_THREADS=512"],
     "t1024": ["RT_EXTEND_THREADS=1024"],
     "c128": ["RT_CHUNK=128"],
+    "longwalk": ["RT_DEBUG_LONGWALK=1"],
+    "c256": ["RT_CHUNK=256"],
+    "proot": ["RT_PARK_READS_ROOT=1"],
+    "b16r16": ["RT_LEAF_BATCH=16", "RT_REFILL_MIN=16"],
     "c512": ["RT_CHUNK=512"],
+    "c1024": ["RT_CHUNK=1024"],
+    "c2048": ["RT_CHUNK=2048"],
+    "c4096": ["RT_CHUNK=4096"],
+    "c8192": ["RT_CHUNK=8192"],
+    "c2048b24r24": ["RT_CHUNK=2048", "RT_LEAF_BATCH=24", "RT_REFILL_MIN=24"],
     "s2": ["RT_STEPS=2"],
     "s8": ["RT_STEPS=8"],
     "b8": ["RT_LEAF_BATCH=8"],
