@@ -178,11 +178,13 @@ def main():
         # HBM traffic of k_extend proper: bytes/segment from the committed PMC passes (profiles/r01_pmc_traffic.json:
         # rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this bench, FETCH doubled for gfx950) x the
         # segments one launch of THIS run processed. bench.py cannot collect PMC counters on itself.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pmc = None, None, {}
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = round(tj["kernels"]["k_extend"]["bytes_per_segment"] * seg / max(1, launches) / 1e6, 3)
-            traffic_src = "MB per launch = 41.7 B/segment (PMC: 32.5 read + 9.2 written, profiles/r01_pmc_traffic.json) x segments_per_launch"
+            pmc = tj["kernels"]["k_extend"]
+            traffic = round(pmc["bytes_per_segment"] * seg / max(1, launches) / 1e6, 3)
+            traffic_src = (f"MB per launch = {pmc['bytes_per_segment']} B/segment (PMC: {pmc['read_bytes_per_segment']} read + "
+                           f"{pmc['write_bytes_per_segment']} written, profiles/r01_pmc_traffic.json) x segments_per_launch")
         except Exception:
             pass
         out["roofline"] = {
@@ -193,8 +195,11 @@ def main():
             "bytes_per_segment": round(b_seg, 1), "node_tests_per_segment": round(vn, 2), "sphere_tests_per_segment": round(vp, 2),
             "segments_per_sample": round(seg_per_sample, 3),
             "note": "achieved = algorithmic bytes (node + sphere records the reference-order traversal touches, + ray read + hit write) / k_extend "
-                    "time from HIP events; the 24 KB scene is LDS-resident, so measured HBM traffic is the 41.7 B/segment of ray state only: the "
-                    "kernel is bound by dependent LDS-read -> slab-test chains, not by HBM (DESIGN.md section 5)",
+                    "time from HIP events. The 24 KB scene is LDS-resident, so the HBM traffic of the kernel is the ray state only (`traffic`, far "
+                    "below the algorithmic bytes) and frac > 1 says nothing about HBM: the kernel is bound by VALU issue (valu_busy ~1.0 in the "
+                    "PMC passes: SQ_INSTS_VALU x 4 cycles = every SIMD cycle of the kernel), 17 VALU per node visit at 76 % lane use (DESIGN.md section 5)",
+            "valu": {"busy": pmc.get("valu_busy"), "lane_utilisation": pmc.get("valu_lane_utilisation"),
+                     "wave_instructions_per_segment": pmc.get("valu_wave_instructions_per_segment"), "source": "profiles/r01_pmc_traffic.json"},
             "extend_ms_per_step": round(ext_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
             # whole-path figure in SURVEY 8(d)'s units: B_sample = sum over segments (V_n*32 + V_p*20 + 128) + 12
             "whole_path": {"bytes_per_sample": round(seg_per_sample * (b_seg_trav + 128) + 12, 1),
@@ -218,7 +223,7 @@ def main():
             torch.cuda.synchronize()
             d2 = time.perf_counter() - t1
             out["variants"] = {"bvh_sah": {"value": round(s2["samples"] / d2 / 1e6, 1), "unit": "Msamples/s", "extend_ms": round(s2["extend_ms"], 1),
-                                           "note": "identical frame (tests/test_gpu_scenes.py::test_sah_builder_gives_the_same_picture), ~23 node tests/segment instead of 41.6"}}
+                                           "note": "identical frame (tests/test_gpu_scenes.py::test_sah_builder_gives_the_same_picture), ~23 node tests/segment instead of 41.7"}}
         except Exception as e:   # never let the extra line break the contract line
             out["variants"] = {"bvh_sah": {"error": str(e)}}
 

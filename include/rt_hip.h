@@ -185,7 +185,7 @@ typedef struct RtParams {
     uint32_t tile_size;           /* 0 = default (32) */
     uint32_t shard_index;
     uint32_t shard_count;
-    uint32_t pool_slots;          /* paths in flight; 0 = library default */
+    uint32_t pool_slots;          /* paths in flight; 0 = one per work item, up to 2^28 and to 70 % of the free device memory */
 } RtParams;
 
 #define RT_N_PRIM_TYPES 6  /* sphere, moving sphere, rect, triangle, medium, instance transform */

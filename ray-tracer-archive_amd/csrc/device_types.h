@@ -45,11 +45,11 @@ inline uint32_t make_leaf(uint32_t type, uint32_t first, uint32_t count) { retur
 // record without a box has c = 0, h = inf. One extra
 struct NodeDev { float cx, cy, hx, hy, cz, hz; uint32_t skip_bytes, leaf; };
 static_assert(sizeof(NodeDev) == 32, "device node record is 32 bytes");
-// Record stride. In HBM records are packed. A scene that k_extend keeps in LDS is laid out with 48-byte
-// records (16 bytes of padding): the two 16-byte halves of 32-byte records only ever land on 8 of the 16
-// slot columns of the LDS bank row, which doubles the ds_read_b128 bank conflicts of lanes at different nodes.
+// Record stride: packed, in HBM and in LDS. (48-byte records in LDS halve the ds_read_b128 bank conflicts of lanes at
+// different nodes — 32-byte records only reach 8 of the 16 slot columns — but measured no faster: the visit is bound
+// by VALU issue, and the larger copy pushed the book-2 scene out of LDS. -DRT_NODE_STRIDE_LDS=48 keeps the experiment.)
 #ifndef RT_NODE_STRIDE_LDS
-#define RT_NODE_STRIDE_LDS 48
+#define RT_NODE_STRIDE_LDS 32
 #endif
 constexpr uint32_t NODE_STRIDE_HBM = 32, NODE_STRIDE_LDS = RT_NODE_STRIDE_LDS;
 // lane states of k_extend kept in the `pend` word (leaf type 0 = no primitive work):

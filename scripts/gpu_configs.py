@@ -11,7 +11,7 @@ out = {}
 def run(tag, hs, W, H, spp, aspect=None, png=True):
     t = time.time(); scene = ctx.upload(hs.desc); t_up = time.time() - t
     cam = hs.camera(aspect or W / H)
-    ctx.render(scene, cam, p.make_params(W, H, max(1, spp // 20)))
+    ctx.render(scene, cam, p.make_params(W, H, spp))
     t = time.time(); img, st = ctx.render(scene, cam, p.make_params(W, H, spp, flags=2)); dt = time.time() - t
     _, c = ctx.render(scene, cam, p.make_params(W, H, max(1, spp // 50), flags=1))
     out[tag] = dict(width=W, height=H, spp=spp, seconds=round(dt, 3), msamples_per_s=round(W * H * spp / dt / 1e6, 1), upload_s=round(t_up, 2),

@@ -36,7 +36,7 @@ VARIANTS = {
     "bs2": ["RT_BLOCK_SHIFT=2"],
     "bs3": ["RT_BLOCK_SHIFT=3"],
     "bs5": ["RT_BLOCK_SHIFT=5"],
-    "st32": ["RT_NODE_STRIDE_LDS=32"],
+    "st48": ["RT_NODE_STRIDE_LDS=48"],
     "o5": ["RT_EXTEND_PER_CU_MAX=5"],
     "o4": ["RT_EXTEND_PER_CU_MAX=4"],
     "o3": ["RT_EXTEND_PER_CU_MAX=3"],
