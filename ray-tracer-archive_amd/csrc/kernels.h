@@ -43,6 +43,18 @@ struct PoolDev {
     rtd::Float4* s0; uint4* s3; rtd::Float4* s1;   // s0 = (T.rgb, work item); s3 = (rng lo, hi, sample << 8 | depth, x | y << 16); s1 = acc (block_shift != 0 only)
 };
 
+// Exact u32 division by a launch-invariant divisor: q = (t + ((n - t) >> s1)) >> s2 with t = umulhi(m, n)
+// (Granlund-Montgomery round-up; five instructions instead of the ~35 of a hardware-less u32 divide).
+struct FastDiv { uint32_t m, s1, s2, d; };
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f{0u, 0u, 0u, d};
+    if (d <= 1u) return f;                       // n / 1: t = 0, q = n
+    uint32_t l = 0; while ((1ull << l) < d) ++l; // ceil(log2 d), 1..32
+    f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1ull);
+    f.s1 = 1u; f.s2 = l - 1u;
+    return f;
+}
+
 struct RenderDev {
     // camera.rs:6-18 in f32
     float cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3], cam_u[3], cam_v[3];
@@ -58,6 +70,8 @@ struct RenderDev {
     uint32_t total_items;   // in-image pixels of this shard * n_blocks
     uint32_t n_local_tiles;
     const uint32_t* tile_prefix;  // [n_local_tiles + 1]: in-image pixels in local tiles before lt
+    uint32_t tile_slack;          // the tile of pixel q is within [q / ts^2, q / ts^2 + tile_slack] (edge tiles are clipped)
+    FastDiv div_ts2, div_tiles_x, div_sq_row, div_item_tile;   // ts^2, tiles_x, ts / 8, ts^2 * n_blocks
     rtd::Float4* blocksum;  // [total_items]: RGB sum of one work item's samples
 };
 

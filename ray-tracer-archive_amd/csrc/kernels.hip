@@ -646,9 +646,10 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 // maps to a pixel inside the image (edge tiles are clipped, not padded).
 struct WorkItem { uint32_t x, y, blk; };
 struct TileGeom { uint32_t x0, y0, w, h; };
+DEVI uint32_t fdivu(uint32_t n, const FastDiv& f) { const uint32_t t = __umulhi(f.m, n); return (t + ((n - t) >> f.s1)) >> f.s2; }
 DEVI TileGeom tile_geom(const RenderDev& rd, uint32_t lt) {
     const uint32_t tile = rd.shard_index + lt * rd.shard_count;
-    const uint32_t tx = tile % rd.tiles_x, ty = tile / rd.tiles_x;
+    const uint32_t ty = fdivu(tile, rd.div_tiles_x), tx = tile - ty * rd.tiles_x;
     TileGeom g;
     g.x0 = tx * rd.tile_size; g.y0 = ty * rd.tile_size;
     g.w = min(rd.tile_size, rd.width - g.x0); g.h = min(rd.tile_size, rd.height - g.y0);
@@ -658,13 +659,16 @@ DEVI void tile_pixel(const RenderDev& rd, const TileGeom& g, uint32_t p, uint32_
     if (g.w == rd.tile_size && g.h == rd.tile_size) {
         // full tile: 8x8 pixel squares, so a wave's 64 consecutive items cover one square
         const uint32_t sq = p >> 6, in = p & 63u, sq_per_row = rd.tile_size >> 3;
-        px = (sq % sq_per_row) * 8u + (in & 7u); py = (sq / sq_per_row) * 8u + (in >> 3);
-    } else { px = p % g.w; py = p / g.w; }
+        const uint32_t row = fdivu(sq, rd.div_sq_row);
+        px = (sq - row * sq_per_row) * 8u + (in & 7u); py = row * 8u + (in >> 3);
+    } else { py = p / g.w; px = p - py * g.w; }
 }
 DEVI uint32_t find_tile(const RenderDev& rd, uint64_t key, uint32_t scale, uint32_t lo) {
-    // largest lt with tile_prefix[lt] * scale <= key
-    uint32_t hi = rd.n_local_tiles - 1u;
-    lo = min(lo, hi);
+    // largest lt with tile_prefix[lt] * scale <= key. `lo` = key / (scale * ts^2) is exact when every tile before is
+    // full; clipped edge tiles move the answer up by at most tile_slack (host: clipped pixels / ts^2 + 1)
+    const uint32_t last = rd.n_local_tiles - 1u;
+    lo = min(lo, last);
+    uint32_t hi = min(last, lo + rd.tile_slack);
     while (lo < hi) {
         const uint32_t mid = (lo + hi + 1u) >> 1;
         if ((uint64_t)rd.tile_prefix[mid] * scale <= key) lo = mid; else hi = mid - 1u;
@@ -672,13 +676,13 @@ DEVI uint32_t find_tile(const RenderDev& rd, uint64_t key, uint32_t scale, uint3
     return lo;
 }
 DEVI WorkItem decode_work(const RenderDev& rd, uint32_t w) {
-    const uint32_t ts2 = rd.tile_size * rd.tile_size;
-    const uint32_t lt = find_tile(rd, w, rd.n_blocks, w / (ts2 * rd.n_blocks));
+    const uint32_t lt = find_tile(rd, w, rd.n_blocks, fdivu(w, rd.div_item_tile));
     const TileGeom g = tile_geom(rd, lt);
+    const bool full = g.w == rd.tile_size && g.h == rd.tile_size;
     const uint32_t valid = g.w * g.h;
     const uint32_t r = w - rd.tile_prefix[lt] * rd.n_blocks;
     WorkItem it;
-    it.blk = r / valid;
+    it.blk = full ? fdivu(r, rd.div_ts2) : r / valid;
     uint32_t px, py;
     tile_pixel(rd, g, r - it.blk * valid, px, py);
     it.x = g.x0 + px; it.y = g.y0 + py;
@@ -1120,7 +1124,7 @@ __global__ void __launch_bounds__(256) k_resolve(RenderDev rd, float* __restrict
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per in-image pixel of this shard
     if (gid >= rd.tile_prefix[rd.n_local_tiles]) return;
     const uint32_t ts2 = rd.tile_size * rd.tile_size;
-    const uint32_t lt = find_tile(rd, gid, 1u, gid / ts2);
+    const uint32_t lt = find_tile(rd, gid, 1u, fdivu(gid, rd.div_ts2));
     const TileGeom g = tile_geom(rd, lt);
     const uint32_t valid = g.w * g.h, p = gid - rd.tile_prefix[lt];
     const uint64_t base = (uint64_t)rd.tile_prefix[lt] * rd.n_blocks + p;

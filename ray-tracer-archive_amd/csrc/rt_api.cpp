@@ -274,6 +274,14 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     if (total_items >= (1ull << 32) - (1ull << 28)) return set_err(ctx, RT_ERR_INVALID, "too many work items for one shard (image too large)");
     rd.total_items = (uint32_t)total_items;
     rd.n_local_tiles = tl.n_local;
+    {   // launch-invariant divisors of the item -> (tile, pixel, sample) decode, and how far clipped edge tiles can move a tile index
+        const uint64_t ts2 = (uint64_t)tl.ts * tl.ts, item_tile = ts2 * rd.n_blocks;
+        rd.div_ts2 = rtk::make_fastdiv((uint32_t)ts2); rd.div_tiles_x = rtk::make_fastdiv(tl.tiles_x); rd.div_sq_row = rtk::make_fastdiv(std::max(1u, tl.ts >> 3));
+        const bool fits = item_tile <= 0xFFFFFFFFull;
+        rd.div_item_tile = rtk::make_fastdiv(fits ? (uint32_t)item_tile : 0xFFFFFFFFu);
+        const uint64_t clipped = (uint64_t)tl.n_local * ts2 - valid_pixels;
+        rd.tile_slack = fits ? (uint32_t)std::min<uint64_t>(tl.n_local, clipped / ts2 + 1) : tl.n_local;
+    }
 
     if (stats) { std::memset(stats, 0, sizeof(*stats)); }
     const auto t_begin = clk::now();
