@@ -189,7 +189,7 @@ DEVI bool sphere_certain_miss(V3 o, V3 d, float a, V3 c, float r) {
     if (det < -2e-6f * fmaf(a, scale, hb * hb)) return true;                          // no real root, with margin
     return hb > 0.f && hb * hb > 1e-10f * (l2 * a) && cc > 4e-6f * scale;                // outside and pointing away: both roots < 0
 }
-DEVI bool sphere_roots(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax, float& t) {
+DEVI bool sphere_two_roots(V3 o, V3 d, float a, V3 c, float r, float& t_near, float& t_far) {
     const double ocx = (double)o.x - (double)c.x, ocy = (double)o.y - (double)c.y, ocz = (double)o.z - (double)c.z;
     const double half_b = fma(ocz, (double)d.z, fma(ocy, (double)d.y, ocx * (double)d.x));
     const double cc = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -(double)r * (double)r)));
@@ -200,7 +200,12 @@ DEVI bool sphere_roots(V3 o, V3 d, float a, V3 c, float r, float tmin, float tma
     const float q = hbf > 0.f ? -(hbf + sq) : (sq - hbf);   // -half_b -/+ sqrt(det) without cancellation
     if (q == 0.f) return false;                              // double root at t = 0
     const float tq = q * fast_rcp(a), tc = ccf * fast_rcp(q);   // the roots carry ~2 ulp, like every f32 quantity around them
-    const float t_near = hbf > 0.f ? tq : tc, t_far = hbf > 0.f ? tc : tq;   // (-hb - sq)/a and (-hb + sq)/a
+    t_near = hbf > 0.f ? tq : tc; t_far = hbf > 0.f ? tc : tq;   // (-hb - sq)/a and (-hb + sq)/a
+    return true;
+}
+DEVI bool sphere_roots(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax, float& t) {
+    float t_near, t_far;
+    if (!sphere_two_roots(o, d, a, c, r, t_near, t_far)) return false;
     float root = t_near;
     if (root < tmin || tmax < root) {
         root = t_far;
@@ -285,10 +290,22 @@ DEVI bool medium_hit(const SceneDev& sc, const rtd::Medium& m, V3 ow, V3 dw, flo
     if (m.boundary_xform) xform_ray(sc.xforms[m.boundary_xform], ow, dw, o, d);
     const float a = len2(d);
     float t1, t2;
-    if (!boundary_hit(sc, m, o, d, a, -kInf, kInf, t1)) return false;
-    // constant_medium.rs:37 searches from rec1.t + 0.0001; in f32 that increment vanishes once |t1| > 2048
-    // (ulp 2.4e-4) and the probe would find the same root again, so the bound is made strictly larger than t1
-    if (!boundary_hit(sc, m, o, d, a, fmaxf(t1 + 0.0001f, nextafterf(t1, kInf)), kInf, t2)) return false;
+    // constant_medium.rs:33-37: the boundary is probed over (-inf, inf) and again from rec1.t + 0.0001. In f32 that
+    // increment vanishes once |t1| > 2048 (ulp 2.4e-4) and the second probe would find the same root again, so its
+    // bound is made strictly larger than t1.
+    if (m.boundary_type == rtd::LT_SPHERE) {
+        // a sphere boundary: both probes of Sphere::hit come out of one discriminant (near root, then the far root)
+        const Float4 s = sc.spheres[m.boundary_first];
+        float t_near, t_far;
+        if (!sphere_two_roots(o, d, a, f4xyz(s), s.w, t_near, t_far)) return false;
+        t1 = t_near;
+        const float lo2 = fmaxf(t1 + 0.0001f, nextafterf(t1, kInf));
+        t2 = t_near;
+        if (t2 < lo2) { t2 = t_far; if (t2 < lo2) return false; }
+    } else {
+        if (!boundary_hit(sc, m, o, d, a, -kInf, kInf, t1)) return false;
+        if (!boundary_hit(sc, m, o, d, a, fmaxf(t1 + 0.0001f, nextafterf(t1, kInf)), kInf, t2)) return false;
+    }
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
@@ -411,6 +428,20 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #else
 #define STAMP(x)
 #endif
+    // the two halves of the node record at byte offset `off`
+    auto load_record = [&](uint32_t off, float4& n0, float4& n1) {
+        if constexpr (LDS) {
+            // k_extend has no static LDS, so the staged copy starts at LDS address 0: the record's offset IS its address
+            // (saves the add of a link-time base per visit; the staging loop above writes through `lds`, the same bytes)
+            typedef float F4V __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(3))) F4V* lds_f4;
+            const F4V a0 = *reinterpret_cast<lds_f4>(off), a1 = *reinterpret_cast<lds_f4>(off + 16u);
+            n0 = make_float4(a0.x, a0.y, a0.z, a0.w); n1 = make_float4(a1.x, a1.y, a1.z, a1.w);
+        } else {
+            n0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off);
+            n1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off + 16u);
+        }
+    };
     // One outer iteration = one refill. The ray records of the next 64 queue slots are loaded into No/Nd at
     // the END of a refill (one unconditional definition per iteration, so hipcc keeps the loads in flight) and
     // handed out at the NEXT refill by __shfl (ds_bpermute): the wave no longer parks on HBM latency with
@@ -484,17 +515,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             const uint32_t off = node;      // a parked lane re-reads its own next record (an idle one record 0) and ignores it
 #endif
             float4 n0, n1;
-            if constexpr (LDS) {
-                // k_extend has no static LDS, so the staged copy starts at LDS address 0: the record's offset IS its address
-                // (saves the add of a link-time base per visit; the staging loop above writes through `lds`, the same bytes)
-                typedef float F4V __attribute__((ext_vector_type(4)));
-                typedef const __attribute__((address_space(3))) F4V* lds_f4;
-                const F4V a0 = *reinterpret_cast<lds_f4>(off), a1 = *reinterpret_cast<lds_f4>(off + 16u);
-                n0 = make_float4(a0.x, a0.y, a0.z, a0.w); n1 = make_float4(a1.x, a1.y, a1.z, a1.w);
-            } else {
-                n0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off);
-                n1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off + 16u);
-            }
+            load_record(off, n0, n1);
             const uint32_t skip = __float_as_uint(n1.z), leaf = __float_as_uint(n1.w);
             // Aabb::hit (aabb.rs:31-55, interval carried across axes), on (centre, half extent): 4 packed ops for x and y,
             // one packed FMA + add/sub for z. min3/max3 ignore a NaN operand (0*inf), which keeps the box — conservative,
