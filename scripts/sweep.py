@@ -27,6 +27,9 @@ VARIANTS = {
     "c2048b24r24": ["RT_CHUNK=2048", "RT_LEAF_BATCH=24", "RT_REFILL_MIN=24"],
     "s2": ["RT_STEPS=2"],
     "s8": ["RT_STEPS=8"],
+    "s6": ["RT_STEPS=6"],
+    "s3": ["RT_STEPS=3"],
+    "s5": ["RT_STEPS=5"],
     "b8": ["RT_LEAF_BATCH=8"],
     "b24": ["RT_LEAF_BATCH=24"],
     "b32": ["RT_LEAF_BATCH=32"],
@@ -37,6 +40,7 @@ VARIANTS = {
     "bs3": ["RT_BLOCK_SHIFT=3"],
     "bs5": ["RT_BLOCK_SHIFT=5"],
     "st48": ["RT_NODE_STRIDE_LDS=48"],
+    "o6": ["RT_EXTEND_PER_CU_MAX=6"],
     "o5": ["RT_EXTEND_PER_CU_MAX=5"],
     "o4": ["RT_EXTEND_PER_CU_MAX=4"],
     "o3": ["RT_EXTEND_PER_CU_MAX=3"],
