@@ -187,8 +187,21 @@ def main():
                            f"{pmc['write_bytes_per_segment']} written, profiles/r01_pmc_traffic.json) x segments_per_launch")
         except Exception:
             pass
+        # a measured HBM figure beside the spec peak: device-to-device copy of 2 GiB (read + write), best of 5
+        copy_gbs = None
+        try:
+            src = torch.empty(1 << 29, dtype=torch.float32, device=dev); dst = torch.empty_like(src)
+            dst.copy_(src); torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(5):
+                t1 = time.perf_counter(); dst.copy_(src); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t1)
+            copy_gbs = round(2 * src.numel() * 4 / best / 1e9, 1)
+            del src, dst
+        except Exception:
+            pass
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "measured_copy_gbs": copy_gbs,
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "MB/launch", "traffic_source": traffic_src,
             "algorithmic_mb_per_launch": round(b_seg * seg / max(1, launches) / 1e6, 3),
             "avg_launch_ms": round(ext_ms / max(1, launches), 4), "launches": launches, "segments_per_launch": round(seg / max(1, launches), 1),

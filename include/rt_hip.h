@@ -168,7 +168,7 @@ typedef enum RtNanPolicy {
 enum {
     RT_FLAG_COUNTERS = 1u,  /* count AABB tests and primitive tests on the device (slower) */
     RT_FLAG_TIMING = 2u,    /* bracket every kernel launch with HIP events (RtStats *_ms) */
-    RT_FLAG_SAMPLE_BLOCKS = 4u  /* work items of 16 consecutive samples of a pixel, as for images above 2^30 samples
+    RT_FLAG_SAMPLE_BLOCKS = 4u  /* work items of 16 consecutive samples of a pixel, as for images of 2^32 - 2^28 samples and more
                                    (default below that: one sample per item). Per-pixel sums then differ in the last bits. */
 };
 

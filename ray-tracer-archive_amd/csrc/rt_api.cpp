@@ -19,6 +19,7 @@
 namespace {
 
 thread_local std::string g_last_error;
+constexpr uint64_t kMaxItems = (1ull << 32) - (1ull << 28);   // work items of one render (u32 index, with head room for the allocator's overshoot)
 constexpr size_t kLdsSceneBudget = 64 * 1024;   // nodes + sphere records staged per workgroup
 
 struct DevBuf {
@@ -259,19 +260,20 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         prefix[lt + 1] = prefix[lt] + w * h;
     }
     const uint64_t valid_pixels = prefix[tl.n_local];
-    // samples per work item: 1 whenever the whole IMAGE (all shards, so that every shard sums the same way) has at most
-    // 2^30 samples — a path is then one sample, nothing is regenerated mid-flight and the radiance of every sample
-    // is stored on its own (16 GB of block sums at the limit; this is a 288 GB device). Larger renders group 2, 4, ...
-    // consecutive samples of a pixel into one item.
+    // samples per work item: 1 whenever the whole IMAGE (all shards, so that every shard sums the same way) has fewer
+    // than 2^32 - 2^28 samples (what a u32 item index can address) — a path is then one sample, nothing is regenerated
+    // mid-flight and the radiance of every sample is stored on its own (16 B each: 64 GB for an unsharded render at the
+    // limit; this is a 288 GB device, and a sharded render holds its own shard's samples only). Larger renders group
+    // 2, 4, ... consecutive samples of a pixel into one item.
     uint32_t block_shift = (prm->flags & RT_FLAG_SAMPLE_BLOCKS) ? 4u : 0u;
     while ((1u << block_shift) > rd.spp && block_shift > 0) --block_shift;
     {
         const uint64_t image_pixels = (uint64_t)prm->width * prm->height;
-        while ((1u << block_shift) < rd.spp && image_pixels * ((rd.spp + (1u << block_shift) - 1) >> block_shift) > (1ull << 30)) ++block_shift;
+        while ((1u << block_shift) < rd.spp && image_pixels * ((rd.spp + (1u << block_shift) - 1) >> block_shift) >= kMaxItems) ++block_shift;
     }
     rd.block_shift = block_shift; rd.n_blocks = (rd.spp + (1u << block_shift) - 1) >> block_shift;
     const uint64_t total_items = valid_pixels * rd.n_blocks;
-    if (total_items >= (1ull << 32) - (1ull << 28)) return set_err(ctx, RT_ERR_INVALID, "too many work items for one shard (image too large)");
+    if (total_items >= kMaxItems) return set_err(ctx, RT_ERR_INVALID, "too many work items for one shard (image too large)");
     rd.total_items = (uint32_t)total_items;
     rd.n_local_tiles = tl.n_local;
     {   // launch-invariant divisors of the item -> (tile, pixel, sample) decode, and how far clipped edge tiles can move a tile index

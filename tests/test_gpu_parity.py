@@ -82,7 +82,7 @@ def test_bit_exact_invariances(pkg, gpu, book1):
         assert np.array_equal(D.assemble(base, np.stack(parts), world), a)
     f, _ = gpu.render(scene, cam, pkg.make_params(W, H, SPP, seed=6))
     assert not np.array_equal(a, f)
-    # work items of 16 samples (the layout of images above 2^30 samples; paths are regenerated in flight and carry a
+    # work items of 16 samples (the layout of images of 2^32 - 2^28 samples and more; paths are regenerated in flight and carry a
     # running sum): the same samples, summed block-wise, so equal to rounding; bit-stable against the pool size too
     SB = pkg._abi.RT_FLAG_SAMPLE_BLOCKS
     g16, _ = gpu.render(scene, cam, pkg.make_params(W, H, SPP, seed=5, flags=SB))
