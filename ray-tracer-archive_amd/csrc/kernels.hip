@@ -568,7 +568,22 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         // ---- primitive pass: when enough lanes hold a leaf, or nobody can walk any further ----
         const uint64_t pm = __ballot((pend >> 28) != 0u);
         const bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(pend == 0u) == 0ull);
-        if (do_prims && (pend >> 28) != 0u) {
+        // Scenes with four or more primitive kinds (book-2 final: spheres, a moving sphere, rects, media): a pass serves ONE
+        // kind, the one most lanes wait with; the others stay parked and win a later pass. Every kind's code then runs with
+        // as many lanes as the wave can give it instead of several kinds back to back with a handful of lanes each
+        // (26 % VALU lane use before; k_extend 1039 -> 620 ms on that scene). With two or three kinds the extra passes cost
+        // more than they save (Cornell +2 %, the 1 M-sphere + mesh scene +10 %), hence the scene-level switch.
+        uint32_t serve = 0u;   // 0: every kind
+        if (FEAT != 0u && sc.n_prim_kinds >= 4u && do_prims) {
+            const uint32_t ty = pend >> 28;
+            uint32_t best = 0u;
+#pragma unroll
+            for (uint32_t k = rtd::LT_SPHERE; k <= rtd::LT_MEDIUM; ++k) {
+                const uint32_t c = (uint32_t)__popcll(__ballot(ty == k));
+                if (c > best) { best = c; serve = k; }
+            }
+        }
+        if (do_prims && (pend >> 28) != 0u && (serve == 0u || (pend >> 28) == serve)) {
             const uint32_t type = pend >> 28, cnt = (pend >> 24) & 15u, first = pend & rtd::LEAF_MAX_FIRST;
             pend = 0u;
             if (type == rtd::LT_SPHERE) {

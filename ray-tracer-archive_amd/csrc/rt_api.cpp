@@ -199,6 +199,8 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     if (r != RT_OK) { rt_scene_destroy(ctx, s); return r; }
     rtk::SceneDev& d = s->dev;
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
+    d.n_prim_kinds = (cs.sphere_meta.empty() ? 0u : 1u) + (cs.moving_meta.empty() ? 0u : 1u) + (cs.rect_meta.empty() ? 0u : 1u) +
+                     (cs.tri_meta.empty() ? 0u : 1u) + (cs.media.empty() ? 0u : 1u);
     d.spheres = (const rtd::Float4*)s->spheres.p; d.sphere_meta = (const uint32_t*)s->sphere_meta.p; d.n_spheres = (uint32_t)cs.spheres.size();
     d.moving = (const rtd::Float4*)s->moving.p; d.moving_meta = (const uint32_t*)s->moving_meta.p;
     d.rects = (const rtd::Float4*)s->rects.p; d.rect_meta = (const uint32_t*)s->rect_meta.p;
