@@ -3,8 +3,9 @@
 // Wavefront formulation of the reference's per-sample loop (main.rs:751-763) and ray_color
 // recursion (main.rs:63-139):
 //
-//   k_generate : fills the path pool — each slot takes a work item (pixel, block of samples) and
-//                builds its first camera ray (Camera::get_ray, camera.rs:60-70).
+//   k_generate : fills the path pool — each slot takes a work item (one sample of a pixel; a block of 2^block_shift
+//                samples only for images too large for one item per sample) and builds its first camera ray
+//                (Camera::get_ray, camera.rs:60-70).
 //   k_extend   : world.hit (main.rs:74) for every ray in the pool. Persistent waves pull rays from
 //                the SoA queue in HBM; a lane that finishes its ray refills from the wave's chunk
 //                (wave64 __ballot + mbcnt prefix), so lanes stay busy although rays need very
@@ -12,11 +13,11 @@
 //                BVH (device_types.h) in the reference's order (bvh.rs:134-143); nodes and sphere
 //                records are staged in LDS when they fit.
 //   k_shade    : everything after world.hit for one segment: emitted / scatter / pdf sampling
-//                (main.rs:78-138), throughput update, next ray; finished samples accumulate into
-//                the slot's block sum and the slot regenerates a camera ray for its next sample or
-//                draws a new work item. Survivors are written to the other pool densely
-//                (__ballot/popc compaction).
-//   k_resolve  : sums each pixel's block sums in block order (deterministic, no float atomics).
+//                (main.rs:78-138), throughput update, next ray; a finished sample is stored as its
+//                item's sum (or added to the slot's running sum, and the slot regenerates a camera ray
+//                for the next sample of a multi-sample item) and the slot draws a new work item.
+//                Survivors are written to the other pool densely (__ballot/popc compaction).
+//   k_resolve  : sums each pixel's item sums in sample order (deterministic, no float atomics).
 //
 // No MFMA: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
