@@ -194,3 +194,21 @@ def test_render_device_into_torch_tensor(pkg, gpu, book1):
     torch.cuda.synchronize()
     gpu.render_device(scene, cam, prm, t.data_ptr())
     assert np.array_equal(t.cpu().numpy().reshape(64, 96, 3), host)
+
+
+def test_parameter_corners_are_pool_independent(pkg, gpu):
+    """Odd corners of RtParams (2x2 image, clipped tiles, depth 1, multi-sample items with a ragged last block) on a
+    sphere-only and a rect/transform/lights scene: the frame, the sample and the segment counts do not depend on the pool."""
+    SB = pkg._abi.RT_FLAG_SAMPLE_BLOCKS
+    for name in ("book1", "cornell"):
+        hs = pkg.HostScene(name, 1)
+        scene = gpu.upload(hs.desc)
+        for (W, H, spp, depth, flags, tile) in [(2, 2, 1, 50, 0, 0), (7, 5, 3, 50, 0, 8), (7, 5, 3, 50, SB, 8), (33, 17, 17, 1, 0, 16),
+                                                (64, 40, 37, 50, SB, 32), (129, 65, 5, 3, 0, 32)]:
+            cam = hs.camera(W / H)
+            a, sa = gpu.render(scene, cam, pkg.make_params(W, H, spp, max_depth=depth, seed=9, flags=flags, tile_size=tile))
+            b, sb = gpu.render(scene, cam, pkg.make_params(W, H, spp, max_depth=depth, seed=9, flags=flags, tile_size=tile, pool_slots=256))
+            assert np.array_equal(a, b) and np.isfinite(a).all(), (name, W, H, spp, depth, flags, tile)
+            assert sa["samples"] == sb["samples"] == W * H * spp and sa["segments"] == sb["segments"]
+            if depth == 1:
+                assert sa["segments"] == W * H * spp      # one world.hit per sample
