@@ -1227,13 +1227,15 @@ static hipError_t launch_extend_t(const LaunchCfg& cfg, const SceneDev& sc, cons
 }
 
 // Kernel variants are compiled for a few feature sets; a scene runs on the smallest one that covers it.
-//   0                    static spheres, Lambertian/Metal/Dielectric (book 1)
-//   F_RECT | F_TRI       + rects and triangles, no wrappers/media/textures/lights (BASELINE config 5)
-//   F_ALL                everything
-constexpr uint32_t kVariantMesh = F_RECT | F_TRI;
+//   0                              static spheres, Lambertian/Metal/Dielectric (book 1)
+//   F_RECT | F_TRI                 + rects and triangles, no wrappers/media/textures/lights (BASELINE config 5)
+//   F_RECT | F_XFORM | F_LIGHTS    + instance transforms and the light sampler (book-3 Cornell box)
+//   F_ALL                          everything
+constexpr uint32_t kVariantMesh = F_RECT | F_TRI, kVariantBox = F_RECT | F_XFORM | F_LIGHTS;
 static uint32_t pick_variant(uint32_t need) {
     if (need == 0u) return 0u;
     if ((need & ~kVariantMesh) == 0u) return kVariantMesh;
+    if ((need & ~kVariantBox) == 0u) return kVariantBox;
     return F_ALL;
 }
 
@@ -1241,8 +1243,9 @@ hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev
                          uint32_t* head, uint32_t* cz, unsigned long long* counters, bool count, hipStream_t stream) {
     const uint32_t v = pick_variant(cfg.features);
 #define RT_EXT(LDSV, F) launch_extend_t<LDSV, F>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream)
-    if (cfg.scene_in_lds) return v == 0u ? RT_EXT(true, 0u) : (v == kVariantMesh ? RT_EXT(true, kVariantMesh) : RT_EXT(true, F_ALL));
-    return v == 0u ? RT_EXT(false, 0u) : (v == kVariantMesh ? RT_EXT(false, kVariantMesh) : RT_EXT(false, F_ALL));
+    if (cfg.scene_in_lds)
+        return v == 0u ? RT_EXT(true, 0u) : v == kVariantMesh ? RT_EXT(true, kVariantMesh) : v == kVariantBox ? RT_EXT(true, kVariantBox) : RT_EXT(true, F_ALL);
+    return v == 0u ? RT_EXT(false, 0u) : v == kVariantMesh ? RT_EXT(false, kVariantMesh) : v == kVariantBox ? RT_EXT(false, kVariantBox) : RT_EXT(false, F_ALL);
 #undef RT_EXT
 }
 
@@ -1262,6 +1265,7 @@ hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev&
     const uint32_t v = pick_variant(cfg.features);
     if (v == 0u) launch_shade_t<0u>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);
     else if (v == kVariantMesh) launch_shade_t<kVariantMesh>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);
+    else if (v == kVariantBox) launch_shade_t<kVariantBox>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);
     else launch_shade_t<F_ALL>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);
     return hipGetLastError();
 }
