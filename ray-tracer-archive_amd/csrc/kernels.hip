@@ -883,7 +883,8 @@ DEVI float light_pdf_value(const rtd::Light& l, V3 o, V3 v, unsigned long long& 
         tests++;
         const V3 c = v3(l.p[0], l.p[1], l.p[2]); const float r = l.p[3];
         float t;
-        if (!sphere_roots(o, v, len2(v), c, r, kTMin, kInf, t)) return 0.f;
+        const float a = len2(v);
+        if (sphere_certain_miss(o, v, a, c, r) || !sphere_roots(o, v, a, c, r, kTMin, kInf, t)) return 0.f;   // same filter + refinement as k_extend
         const float cos_theta_max = fsqrt(1.f - fdiv(r * r, len2(c - o)));
         const float solid_angle = 2.f * kPi * (1.f - cos_theta_max);
         return fdiv(1.f, solid_angle);
