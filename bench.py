@@ -88,8 +88,12 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream(dev)
-    ctx = pkg.Context(local_rank, stream.cuda_stream)   # kernels go on torch's current stream
+    # a real (non-null) torch stream, made current: the library launches on it, torch.zeros / the RCCL gather of
+    # torch.distributed are ordered on it too, and HIP events recorded by the library see every kernel of a step
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx = pkg.Context(local_rank, stream.cuda_stream)
     hs = pkg.HostScene("book1", 1)
     scene = ctx.upload(hs.desc)
     W, H = (args.width, args.height) if args.width and args.height else image_size(n_gpus)

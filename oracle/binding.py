@@ -50,6 +50,8 @@ def lib():
         L.orc_render.argtypes = [vp, vp, vp, C.POINTER(OrcOpts), f64p, C.POINTER(OrcStats)]
         L.orc_render_samples.restype = C.c_int
         L.orc_render_samples.argtypes = [vp, vp, vp, C.POINTER(OrcOpts), f64p, f64p, C.POINTER(OrcStats)]
+        L.orc_render_crops.restype = C.c_int
+        L.orc_render_crops.argtypes = [vp, vp, vp, C.POINTER(OrcOpts), C.c_int32, C.POINTER(C.c_int32), f64p, C.POINTER(OrcStats)]
         L.orc_write_color.restype = None
         L.orc_write_color.argtypes = [f64p, C.c_uint32, C.POINTER(C.c_uint8)]
         L.orc_camera_new.restype = None
@@ -105,6 +107,24 @@ def render(desc, cam, params, precision=64, n_threads=1, rect=None, count=False,
     if rc != 0:
         raise RuntimeError("oracle: " + L.orc_last_error().decode())
     return (out, st.as_dict(), ps) if per_sample else (out, st.as_dict())
+
+
+def render_crops(desc, cam, params, rects, precision=64, n_threads=1, count=False):
+    """Several rectangles (x0, y0, x1, y1) of one frame with one scene build. Returns ([rgb_sum float64 (h,w,3)], [stats dict])."""
+    L = lib()
+    opts = OrcOpts(precision, n_threads, 0, 0, 0, 0, 1 if count else 0, 0)
+    flat = (C.c_int32 * (4 * len(rects)))(*[int(v) for r in rects for v in r])
+    sizes = [(r[3] - r[1], r[2] - r[0]) for r in rects]
+    out = np.zeros(sum(h * w for h, w in sizes) * 3, dtype=np.float64)
+    st = (OrcStats * len(rects))()
+    rc = L.orc_render_crops(C.byref(desc), C.byref(cam), C.byref(params), C.byref(opts), len(rects), flat, out.ctypes.data_as(C.POINTER(C.c_double)), st)
+    if rc != 0:
+        raise RuntimeError("oracle: " + L.orc_last_error().decode())
+    crops, at = [], 0
+    for h, w in sizes:
+        crops.append(out[at:at + h * w * 3].reshape(h, w, 3).copy())
+        at += h * w * 3
+    return crops, [s.as_dict() for s in st]
 
 
 def write_color(pixel_color, spp):

@@ -1036,20 +1036,23 @@ const char* orc_last_error(void) { return g_err.c_str(); }
 namespace orc {
 
 template <class R>
-static int render_t(const RtSceneDesc* desc, const RtCamera* cam_d, const RtParams* prm, const OrcOpts* opt, double* rgb_sum, OrcStats* st,
-                    double* per_sample /* optional: [n_pixels_in_rect][spp][3] */) {
-    Scene<R> sc;
-    if (!sc.load(*desc)) { g_err = "scene: " + sc.error; return -1; }
+static Camera<R> camera_from(const RtCamera* cam_d) {
     Camera<R> cam;
     cam.origin = V<R>(cam_d->origin); cam.lower_left_corner = V<R>(cam_d->lower_left_corner);
     cam.horizontal = V<R>(cam_d->horizontal); cam.vertical = V<R>(cam_d->vertical);
     cam.u = V<R>(cam_d->u); cam.v = V<R>(cam_d->v); cam.w = V<R>(cam_d->w);
     cam.lens_radius = (R)cam_d->lens_radius; cam.time0 = (R)cam_d->time0; cam.time1 = (R)cam_d->time1;
+    return cam;
+}
+
+// The sample loop main.rs:731-784 over the pixel rectangle [x0,x1) x [y0,y1). `compact`: rgb_sum holds the rectangle
+// only (row-major, (y1-y0) x (x1-x0) x 3) instead of the whole H x W frame.
+template <class R>
+static int render_rect(const Scene<R>& sc, const Camera<R>& cam, const RtParams* prm, int nt, bool count, int x0, int y0, int x1, int y1, bool compact,
+                       double* rgb_sum, OrcStats* st, double* per_sample /* optional: [n_pixels_in_rect][spp][3] */) {
     const uint32_t W = prm->width, H = prm->height, spp = prm->samples_per_pixel;
-    int x0 = opt->x0, y0 = opt->y0, x1 = opt->x1, y1 = opt->y1;
-    if (x1 <= x0 || y1 <= y0) { x0 = 0; y0 = 0; x1 = (int)W; y1 = (int)H; }
-    if (x0 < 0 || y0 < 0 || x1 > (int)W || y1 > (int)H) { g_err = "bad rectangle"; return -1; }
-    int nt = std::max(1, opt->n_threads);
+    if (x0 < 0 || y0 < 0 || x1 > (int)W || y1 > (int)H || x1 <= x0 || y1 <= y0) { g_err = "bad rectangle"; return -1; }
+    nt = std::max(1, nt);
     std::vector<Counters> tc(nt);
     auto t_begin = std::chrono::steady_clock::now();
     auto work = [&](int tid) {
@@ -1060,8 +1063,8 @@ static int render_t(const RtSceneDesc* desc, const RtCamera* cam_d, const RtPara
                 double sum[3] = {0, 0, 0};
                 const uint64_t pixel_index = (uint64_t)y * W + (uint64_t)x;
                 for (uint32_t s = 0; s < spp; ++s) {
-                    Rng<R> g; g.base = path_base(prm->seed, pixel_index, s); g.state = g.base; g.segment = 0; g.cnt = opt->count ? &cnt : nullptr;
-                    Ctx<R> cx{&g, opt->count ? &cnt : nullptr, 0};
+                    Rng<R> g; g.base = path_base(prm->seed, pixel_index, s); g.state = g.base; g.segment = 0; g.cnt = count ? &cnt : nullptr;
+                    Ctx<R> cx{&g, count ? &cnt : nullptr, 0};
                     R ju = g.random_double(), jv = g.random_double();
                     R u = ((R)x + ju) / (R)(W - 1);                         // main.rs:752
                     R v = ((R)j + jv) / (R)(H - 1);                         // main.rs:753
@@ -1077,7 +1080,7 @@ static int render_t(const RtSceneDesc* desc, const RtCamera* cam_d, const RtPara
                         double* o = per_sample + (pi * spp + s) * 3; o[0] = cd[0]; o[1] = cd[1]; o[2] = cd[2];
                     }
                 }
-                double* o = rgb_sum + ((size_t)y * W + x) * 3;
+                double* o = compact ? rgb_sum + ((size_t)(y - y0) * (size_t)(x1 - x0) + (size_t)(x - x0)) * 3 : rgb_sum + ((size_t)y * W + x) * 3;
                 o[0] = sum[0]; o[1] = sum[1]; o[2] = sum[2];
             }
         }
@@ -1091,6 +1094,35 @@ static int render_t(const RtSceneDesc* desc, const RtCamera* cam_d, const RtPara
         st->nonfinite_samples = all.nonfinite_samples;
         for (int i = 0; i < RT_N_PRIM_TYPES; ++i) st->prim_tests[i] = all.prim_tests[i];
         st->seconds = secs;
+    }
+    return 0;
+}
+
+template <class R>
+static int render_t(const RtSceneDesc* desc, const RtCamera* cam_d, const RtParams* prm, const OrcOpts* opt, double* rgb_sum, OrcStats* st,
+                    double* per_sample) {
+    Scene<R> sc;
+    if (!sc.load(*desc)) { g_err = "scene: " + sc.error; return -1; }
+    const Camera<R> cam = camera_from<R>(cam_d);
+    int x0 = opt->x0, y0 = opt->y0, x1 = opt->x1, y1 = opt->y1;
+    if (x1 <= x0 || y1 <= y0) { x0 = 0; y0 = 0; x1 = (int)prm->width; y1 = (int)prm->height; }
+    return render_rect<R>(sc, cam, prm, opt->n_threads, opt->count != 0, x0, y0, x1, y1, false, rgb_sum, st, per_sample);
+}
+
+// Several rectangles of one frame with ONE scene build (the 1 M-primitive scene of BASELINE config 5 takes seconds to
+// build): rects = n x (x0, y0, x1, y1); out = the rectangles back to back, compact; stats[n] = counters per rectangle.
+template <class R>
+static int render_crops_t(const RtSceneDesc* desc, const RtCamera* cam_d, const RtParams* prm, const OrcOpts* opt, int n_rects, const int32_t* rects,
+                          double* out, OrcStats* stats) {
+    Scene<R> sc;
+    if (!sc.load(*desc)) { g_err = "scene: " + sc.error; return -1; }
+    const Camera<R> cam = camera_from<R>(cam_d);
+    size_t at = 0;
+    for (int k = 0; k < n_rects; ++k) {
+        const int32_t* q = rects + 4 * k;
+        const int rc = render_rect<R>(sc, cam, prm, opt->n_threads, opt->count != 0, q[0], q[1], q[2], q[3], true, out + at, stats ? stats + k : nullptr, nullptr);
+        if (rc != 0) return rc;
+        at += (size_t)(q[2] - q[0]) * (size_t)(q[3] - q[1]) * 3;
     }
     return 0;
 }
@@ -1111,6 +1143,14 @@ int orc_render_samples(const RtSceneDesc* desc, const RtCamera* cam, const RtPar
     if (!desc || !cam || !prm || !opt || !rgb_sum || !per_sample) { g_err = "null argument"; return -1; }
     if (opt->precision == 32) return orc::render_t<float>(desc, cam, prm, opt, rgb_sum, st, per_sample);
     return orc::render_t<double>(desc, cam, prm, opt, rgb_sum, st, per_sample);
+}
+
+/* n_rects rectangles (x0, y0, x1, y1 each) of one frame, scene built once; out = the rectangles back to back (compact). */
+int orc_render_crops(const RtSceneDesc* desc, const RtCamera* cam, const RtParams* prm, const OrcOpts* opt, int32_t n_rects, const int32_t* rects, double* out,
+                     OrcStats* stats) {
+    if (!desc || !cam || !prm || !opt || !rects || !out || n_rects <= 0) { g_err = "null argument"; return -1; }
+    if (opt->precision == 32) return orc::render_crops_t<float>(desc, cam, prm, opt, n_rects, rects, out, stats);
+    return orc::render_crops_t<double>(desc, cam, prm, opt, n_rects, rects, out, stats);
 }
 
 void orc_write_color(const double* pixel_color, uint32_t samples_per_pixel, uint8_t* out3) { orc::write_color(pixel_color, samples_per_pixel, out3); }

@@ -108,6 +108,7 @@ constexpr uint32_t TEX_INLINE = 0xFFFFFu;   // solid colour folded into the mate
 inline uint32_t make_mat_b(uint32_t kind, uint32_t tex) { return kind | (tex << 4); }
 
 enum TexKind : uint32_t { TK_SOLID = 0, TK_CHECKER = 1, TK_NOISE = 2, TK_IMAGE = 3 };
+constexpr uint32_t MAX_CHECKER_NESTING = 8;   // CheckerTexture inside CheckerTexture (texture.rs:60-69 recurses); deeper graphs and cycles are rejected at compile
 struct Texture { uint32_t kind; int32_t a, b; float scale; float color[3]; uint32_t _pad; };   // 32 B
 struct PerlinTable { Float4 ranvec[256]; uint32_t perm_x[256], perm_y[256], perm_z[256]; };
 struct Image { uint64_t offset; uint32_t width, height; };   // offset into the image byte pool

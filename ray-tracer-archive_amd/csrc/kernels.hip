@@ -841,9 +841,10 @@ DEVI float perlin_turb(const rtd::PerlinTable& pt, V3 p) {                     /
 DEVI V3 texture_value(const SceneDev& sc, uint32_t id, float u, float v, V3 p) {
     rtd::Texture t = sc.textures[id];
     if (t.kind == rtd::TK_CHECKER) {                                           // texture.rs:60-69
+        // `sines` depends on p only, so a checker inside a checker (the reference recurses: odd/even are textures) takes the
+        // same branch at every level; the scene compiler bounds the nesting (scene_compile.cpp: MAX_CHECKER_NESTING)
         const float sines = sinf(10.f * p.x) * sinf(10.f * p.y) * sinf(10.f * p.z);
-        t = sc.textures[sines < 0.f ? t.b : t.a];
-        if (t.kind == rtd::TK_CHECKER) t = sc.textures[t.a];                   // one nesting level only
+        for (uint32_t level = 0; level < rtd::MAX_CHECKER_NESTING && t.kind == rtd::TK_CHECKER; ++level) t = sc.textures[sines < 0.f ? t.b : t.a];
     }
     if (t.kind == rtd::TK_SOLID) return v3(t.color[0], t.color[1], t.color[2]);   // texture.rs:34-38
     if (t.kind == rtd::TK_NOISE) {                                             // texture.rs:90-96

@@ -106,6 +106,17 @@ int validate_params(RtCtx* ctx, const RtParams* p) {
 
 }  // namespace
 
+static int ctx_init(RtCtx* ctx, void* stream) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+    else { HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_count, 64, hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_counters, sizeof(unsigned long long) * 16, hipHostMallocDefault));
+    return RT_OK;
+}
+
 extern "C" {
 
 uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
@@ -120,13 +131,8 @@ int rt_ctx_create(int device_id, void* stream, RtCtx** out_ctx) {
     if (device_id < 0 || device_id >= n) return set_err(nullptr, RT_ERR_INVALID, "device_id out of range");
     RtCtx* ctx = new RtCtx();
     ctx->device = device_id;
-    HIP_TRY(ctx, hipSetDevice(device_id));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
-    if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
-    else { HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
-    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_count, 64, hipHostMallocDefault));
-    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_counters, sizeof(unsigned long long) * 16, hipHostMallocDefault));
+    const int rc = ctx_init(ctx, stream);
+    if (rc != RT_OK) { g_last_error = ctx->err; rt_ctx_destroy(ctx); return rc; }   // nothing of a half-built context survives
     *out_ctx = ctx;
     return RT_OK;
 }
@@ -134,13 +140,13 @@ int rt_ctx_create(int device_id, void* stream, RtCtx** out_ctx) {
 int rt_ctx_destroy(RtCtx* ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& pl : ctx->pool) for (auto& b : pl) b.release();
     ctx->blocksum.release(); ctx->counters.release(); ctx->out_tmp.release(); ctx->tile_prefix.release();
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     if (ctx->h_count) (void)hipHostFree(ctx->h_count);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
 }
@@ -256,12 +262,14 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     rd.tile_size = tl.ts; rd.tiles_x = tl.tiles_x; rd.tiles_y = tl.tiles_y; rd.shard_index = si; rd.shard_count = sc;
     // in-image pixels per local tile (edge tiles are clipped) -> prefix table
     std::vector<uint32_t> prefix(tl.n_local + 1, 0u);
+    uint64_t valid_pixels = 0;
     for (uint32_t lt = 0; lt < tl.n_local; ++lt) {
         const uint32_t tile = si + lt * sc, tx = tile % tl.tiles_x, ty = tile / tl.tiles_x;
         const uint32_t w = std::min(tl.ts, prm->width - tx * tl.ts), h = std::min(tl.ts, prm->height - ty * tl.ts);
-        prefix[lt + 1] = prefix[lt] + w * h;
+        valid_pixels += (uint64_t)w * h;
+        if (valid_pixels > 0xFFFFFFFFull) return set_err(ctx, RT_ERR_INVALID, "more than 2^32 - 1 pixels in one shard (shard the image further)");
+        prefix[lt + 1] = (uint32_t)valid_pixels;
     }
-    const uint64_t valid_pixels = prefix[tl.n_local];
     // samples per work item: 1 whenever the whole IMAGE (all shards, so that every shard sums the same way) has fewer
     // than 2^32 - 2^28 samples (what a u32 item index can address) — a path is then one sample, nothing is regenerated
     // mid-flight and the radiance of every sample is stored on its own (16 B each: 64 GB for an unsharded render at the
@@ -400,11 +408,19 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     return RT_OK;
 }
 
+// A render that fails half way (a HIP error, out of memory) must not leave work or recorded events in flight on the
+// caller's stream: drain it before the error goes back.
+static int render_checked(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, void* d_out, RtStats* stats) {
+    const int r = render_impl(ctx, scene, cam, prm, d_out, stats);
+    if (r != RT_OK) { const std::string keep = ctx->err; (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); ctx->err = keep; g_last_error = keep; }
+    return r;
+}
+
 int rt_render_device(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, void* rgb_sum_device, RtStats* stats) {
     if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
     if (!scene || !cam || !rgb_sum_device) return set_err(ctx, RT_ERR_INVALID, "scene / cam / output is null");
     const int v = validate_params(ctx, prm); if (v != RT_OK) return v;
-    return render_impl(ctx, scene, cam, prm, rgb_sum_device, stats);
+    return render_checked(ctx, scene, cam, prm, rgb_sum_device, stats);
 }
 
 int rt_render(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, float* rgb_sum_host, RtStats* stats) {
@@ -415,7 +431,7 @@ int rt_render(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtPar
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, ctx->out_tmp.ensure(n * sizeof(float)));
     const auto t0 = std::chrono::steady_clock::now();
-    const int r = render_impl(ctx, scene, cam, prm, ctx->out_tmp.p, stats);
+    const int r = render_checked(ctx, scene, cam, prm, ctx->out_tmp.p, stats);
     if (r != RT_OK) return r;
     HIP_TRY(ctx, hipMemcpyAsync(rgb_sum_host, ctx->out_tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -487,6 +503,7 @@ int rt_scene_compile_dump(const RtSceneDesc* desc, void* nodes, uint64_t cap_nod
 int rt_resolve_device(RtCtx* ctx, const void* rgb_sum_device, uint32_t width, uint32_t height, uint32_t spp, void* rgb8_device) {
     if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
     if (!rgb_sum_device || !rgb8_device || spp == 0) return set_err(ctx, RT_ERR_INVALID, "bad argument");
+    if (width == 0 || height == 0 || (uint64_t)width * height * 3u > 0xFFFFFFFFull) return set_err(ctx, RT_ERR_INVALID, "bad image size");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, rtk::launch_write_color((const float*)rgb_sum_device, width * height, spp, (uint8_t*)rgb8_device, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -502,6 +502,18 @@ struct Compiler {
             if (t.kind == RT_TEX_IMAGE && (t.a >= 0 && (uint64_t)t.a >= d.n_images)) { fail("image id out of range"); return; }
             out.textures.push_back(o);
         }
+        // checker-of-checker: the device resolves the chain in a bounded loop; a deeper chain or a cycle cannot be rendered
+        for (uint64_t i = 0; i < d.n_textures; ++i) {
+            if (d.textures[i].kind != RT_TEX_CHECKER) continue;
+            std::vector<std::pair<int32_t, uint32_t>> stack{{(int32_t)i, 1u}};
+            while (!stack.empty()) {
+                const auto [id, depth] = stack.back(); stack.pop_back();
+                const RtTexture& t = d.textures[id];
+                if (t.kind != RT_TEX_CHECKER) continue;
+                if (depth > rtd::MAX_CHECKER_NESTING) { fail("checker textures must be nested at most 8 deep (and without cycles)"); return; }
+                stack.push_back({t.a, depth + 1}); stack.push_back({t.b, depth + 1});
+            }
+        }
         for (uint64_t i = 0; i < d.n_perlins; ++i) {
             rtd::PerlinTable pt{};
             for (int k = 0; k < 256; ++k) {
@@ -512,6 +524,7 @@ struct Compiler {
         }
         for (uint64_t i = 0; i < d.n_images; ++i) {
             const RtImage& im = d.images[i];
+            if (im.data && (im.width == 0 || im.height == 0)) { fail("image with data but a zero dimension"); return; }
             rtd::Image o{}; o.offset = out.image_bytes.size(); o.width = im.data ? im.width : 0; o.height = im.data ? im.height : 0;
             if (im.data) out.image_bytes.insert(out.image_bytes.end(), im.data, im.data + (size_t)im.width * im.height * 3);
             out.images.push_back(o);
@@ -571,7 +584,7 @@ int compile_scene(const RtSceneDesc& desc, CompiledScene& out) {
     out.xforms.push_back(rtd::Xform{0.f, 1.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
     out.wraps.push_back(rtd::Wrap{});
     c.compile_materials();
-    if (!c.ok()) return RT_ERR_INVALID;
+    if (!c.ok()) return out.error.find("must be") != std::string::npos ? RT_ERR_UNSUPPORTED : RT_ERR_INVALID;
     {
         Box3 wb;
         if (c.bbox(desc.world, 0.0, 1.0, wb)) for (int i = 0; i < 3; ++i) c.pad_scale = std::max(c.pad_scale, std::max(std::fabs(wb.mn[i]), std::fabs(wb.mx[i])));

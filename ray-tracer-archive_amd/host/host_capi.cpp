@@ -14,6 +14,8 @@ struct RtHostScene {
     rt::FlatScene flat;
 };
 
+static bool file_readable(const char* path) { FILE* f = std::fopen(path, "r"); if (!f) return false; std::fclose(f); return true; }
+
 extern "C" {
 
 int rt_host_scene_create(const char* name, uint64_t scene_seed, uint64_t arg0, uint64_t arg1, const uint8_t* image, uint32_t image_w, uint32_t image_h,
@@ -22,6 +24,7 @@ int rt_host_scene_create(const char* name, uint64_t scene_seed, uint64_t arg0, u
     *out = nullptr;
     const std::string n(name);
     auto* s = new RtHostScene();
+    bool sah_by_prefix = false;
     if (n == "book1") s->recipe = rt::random_scene(scene_seed, 0, true);
     else if (n == "book1_list") s->recipe = rt::random_scene(scene_seed, 0, false);
     else if (n == "book1_ref") s->recipe = rt::random_scene(scene_seed, 1, true);
@@ -30,6 +33,10 @@ int rt_host_scene_create(const char* name, uint64_t scene_seed, uint64_t arg0, u
     else if (n == "final") s->recipe = rt::final_scene(scene_seed, image, image_w, image_h);
     else if (n == "big" || n == "big_sah") s->recipe = rt::big_scene(scene_seed, (uint32_t)arg0, (uint32_t)arg1);
     else if (n == "book1_sah") s->recipe = rt::random_scene(scene_seed, 0, true);
+    // BASELINE config 5 with an IMPORTED mesh: "big_obj:<path>" / "big_obj_sah:<path>" = arg0 random spheres + the OBJ file's triangles
+    else if ((n.rfind("big_obj:", 0) == 0 || n.rfind("big_obj_sah:", 0) == 0) && !file_readable(n.c_str() + n.find(':') + 1)) { delete s; return RT_ERR_INVALID; }
+    else if (n.rfind("big_obj:", 0) == 0) s->recipe = rt::big_scene(scene_seed, (uint32_t)arg0, 0, n.c_str() + 8);
+    else if (n.rfind("big_obj_sah:", 0) == 0) { s->recipe = rt::big_scene(scene_seed, (uint32_t)arg0, 0, n.c_str() + 12); sah_by_prefix = true; }
     else if (n.rfind("obj:", 0) == 0) {
         // "obj:<path>": the mesh alone on a ground rect (Lambertian 0.5), camera framing the unit-ish model
         rt::HittableList world;
@@ -42,7 +49,7 @@ int rt_host_scene_create(const char* name, uint64_t scene_seed, uint64_t arg0, u
         s->recipe.time0 = 0; s->recipe.time1 = 0;
     }
     else { delete s; return RT_ERR_INVALID; }
-    const bool sah = n.size() > 4 && n.compare(n.size() - 4, 4, "_sah") == 0;
+    const bool sah = sah_by_prefix || (n.find(':') == std::string::npos && n.size() > 4 && n.compare(n.size() - 4, 4, "_sah") == 0);
     s->flat.finish(s->recipe.world, s->recipe.lights, s->recipe.background_mode, s->recipe.background, rt::SceneRng::fin(scene_seed ^ 0xB5AD4ECEDA1CE2A9ull),
                    sah ? RT_BVH_SAH : RT_BVH_REFERENCE);
     *out = s;

@@ -26,6 +26,11 @@ class SceneBuilder:
         self.textures.append(A.RtTexture(A.RT_TEX_CHECKER, e, o, 0, A.RtVec3(0, 0, 0), 0.0))
         return len(self.textures) - 1
 
+    def checker_textures(self, even, odd):
+        """CheckerTexture over two arbitrary textures (texture.rs:41-50: `odd` and `even` are Arc<dyn Texture>, so checkers nest)."""
+        self.textures.append(A.RtTexture(A.RT_TEX_CHECKER, int(even), int(odd), 0, A.RtVec3(0, 0, 0), 0.0))
+        return len(self.textures) - 1
+
     def noise(self, scale, rng):
         """NoiseTexture::construct(scale) with Perlin::new (perlin.rs:14-25) drawn from numpy `rng`."""
         p = A.RtPerlin()

@@ -143,6 +143,36 @@ def test_compile_rejects_malformed_graphs(pkg):
         pkg.compile_info(b.desc(b.bvh([])))                             # empty BVH
 
 
+def test_checker_nesting_and_image_validation(pkg):
+    """Checkers nest (texture.rs:41-69) up to 8 deep on the device; deeper chains and cycles are refused, not mis-rendered.
+    An image with data but a zero dimension is refused (its last row/column index would underflow on the device)."""
+    import ctypes as C
+    A = pkg._abi
+    b = pkg.SceneBuilder()
+    t = b.solid_color((1, 0, 0))
+    for _ in range(8):
+        t = b.checker_textures(t, b.solid_color((0, 1, 0)))
+    s = b.sphere((0, 0, 0), 1, b.lambertian(texture=t))
+    assert pkg.compile_info(b.desc(b.hittable_list([s])))["n_materials"] == 1           # 8 levels: fine
+    t9 = b.checker_textures(t, b.solid_color((0, 0, 1)))
+    s9 = b.sphere((0, 0, 0), 1, b.lambertian(texture=t9))
+    with pytest.raises(pkg.RtError) as e:
+        pkg.compile_info(b.desc(b.hittable_list([s9])))
+    assert e.value.code == A.RT_ERR_UNSUPPORTED
+    b = pkg.SceneBuilder()
+    c = b.checker_textures(0, 0)                                                          # texture 0 = itself: a cycle
+    with pytest.raises(pkg.RtError) as e:
+        pkg.compile_info(b.desc(b.hittable_list([b.sphere((0, 0, 0), 1, b.lambertian(texture=c))])))
+    assert e.value.code == A.RT_ERR_UNSUPPORTED
+    b = pkg.SceneBuilder()
+    px = np.zeros((4, 4, 3), dtype=np.uint8)
+    tid = b.image(px)
+    b.images[0] = A.RtImage(px.ctypes.data_as(C.POINTER(C.c_uint8)), 4, 0)              # data, width 4, height 0
+    with pytest.raises(pkg.RtError) as e:
+        pkg.compile_info(b.desc(b.hittable_list([b.sphere((0, 0, 0), 1, b.lambertian(texture=tid))])))
+    assert e.value.code == A.RT_ERR_INVALID
+
+
 def test_big_scene_compiles_fast(pkg):
     import time
     t = time.time()

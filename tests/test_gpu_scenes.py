@@ -67,6 +67,20 @@ def test_textures_noise_image_checker(pkg, orc, gpu, earth):
     check(pkg, orc, gpu, b.desc(b.bvh(ids)), cam, 96, 64, 8, max_depth=6)
 
 
+def test_nested_checker_textures(pkg, orc, gpu, earth):
+    """CheckerTexture::value recurses into `odd`/`even` (texture.rs:60-69): a checker whose children are a checker, an image and
+    (two levels down) a noise texture. The sign of `sines` is a function of p alone, so every level takes the same branch."""
+    rng = np.random.default_rng(7)
+    b = pkg.SceneBuilder(background=(0.8, 0.8, 0.8))
+    inner2 = b.checker_textures(b.noise(2.0, rng), b.solid_color((0.9, 0.1, 0.1)))
+    inner1 = b.checker_textures(inner2, b.solid_color((0.1, 0.1, 0.9)))
+    outer = b.checker_textures(inner1, b.image(earth[::8, ::8]))
+    ids = [b.sphere((0, 0, 0), 1.5, b.lambertian(texture=outer)), b.sphere((3.2, 0, 0), 1.5, b.lambertian(texture=inner1)),
+           b.sphere((0, -1001.5, 0), 1000, b.lambertian(texture=b.checker_textures(b.solid_color((0.3, 0.3, 0.3)), outer)))]
+    cam = pkg.camera_new((1.5, 1.5, 9), (1.5, 0, 0), (0, 1, 0), 40, 1.5, 0.0, 9.0, 0, 0)
+    check(pkg, orc, gpu, b.desc(b.bvh(ids)), cam, 96, 64, 8, max_depth=6)
+
+
 @pytest.mark.parametrize("wrap", ["translate", "rotate", "both", "flip_both", "double_rotate"])
 def test_instance_wrappers(pkg, orc, gpu, wrap):
     """Translate / RotateY / FlipFace chains, including the reference's RotateY quirk (hittable.rs:173 tests the
