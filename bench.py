@@ -4,10 +4,11 @@
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One step = one full render of the workload (BASELINE.json configs[1]: book-1 random spheres,
-1200x800, 500 spp, depth 50) through the C ABI, output left in HBM. With N GPUs the framebuffer is
-tile-sharded (one process per GPU) and gathered on rank 0 with one RCCL gather; per-GPU work is
-held fixed (weak scaling: the image grows to N x 960k pixels at the same aspect and view).
+One step = one full render of the workload (BASELINE.json configs[1]: book-1 random spheres, 1200x800, 500 spp, depth 50)
+through the C ABI, output left in HBM. With N GPUs (one process per GPU) the framebuffer is tile-sharded and gathered on rank 0 by
+the LIBRARY (rt_render_gather: grouped ncclSend/ncclRecv, RCCL over xGMI, then the root's untile kernel); torch.distributed (gloo)
+only carries the 128-byte RCCL id, the barrier and the max over ranks. Per-GPU work is held fixed (weak scaling: the image grows to
+N x 960k pixels at the same aspect and view); `variants.strong_4096` is the SAME 4096x4096 image at every N (strong scaling).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -20,8 +21,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 78.64: 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions per second (= 157.3 TFLOP/s FP32 FMA / 2)
 NODE_BYTES, SPHERE_BYTES, RAY_BYTES, HIT_BYTES = 32, 20, 32, 8   # SURVEY.md §8(d) record sizes
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_book1.json")
 
 
 def host_cores():
@@ -60,96 +63,132 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--pool-slots", type=int, default=0)
+    ap.add_argument("--strong-spp", type=int, default=64, help="spp of the 4096x4096 strong-scaling leg (0 = skip)")
+    ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
 
     import torch
     import rta
     pkg = rta.load()
     A = pkg._abi
+    from importlib import import_module
+    D = import_module("ray_tracer_archive_amd.distributed")
+    B = import_module("ray_tracer_archive_amd.build")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    # rehearsal on a one-GPU box: RT_BENCH_REHEARSAL=1 puts every rank on cuda:0 and gathers with gloo
-    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        dist.init_process_group(backend="gloo")          # control plane only: RCCL id, barrier, max over ranks
     n_gpus = max(world, 1)
     if args.gpus != n_gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # a real (non-null) torch stream, made current: the library launches on it, torch.zeros / the RCCL gather of
-    # torch.distributed are ordered on it too, and HIP events recorded by the library see every kernel of a step
+    # a real (non-null) torch stream, made current: the library launches on it, and HIP events recorded by the library see
+    # every kernel of a step
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ctx = pkg.Context(local_rank, stream.cuda_stream)
+    gather_path = "single GPU"
+    if n_gpus > 1:
+        D.init_comm(ctx, rank, n_gpus, dist)             # rt_comm_init_rank: the data-path collective lives in the library
+        gather_path = "rt_render_gather: grouped ncclSend/ncclRecv to rank 0 (RCCL, called from csrc/rt_multi.cpp) + untile kernel"
     hs = pkg.HostScene("book1", 1)
     scene = ctx.upload(hs.desc)
     W, H = (args.width, args.height) if args.width and args.height else image_size(n_gpus)
     cam = hs.camera(W / H)
     base = pkg.make_params(W, H, args.spp, max_depth=50, seed=1, flags=A.RT_FLAG_TIMING, pool_slots=args.pool_slots)
-    from importlib import import_module
-    D = import_module("ray_tracer_archive_amd.distributed")
+    frame1 = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if n_gpus == 1 else None
+    stream.synchronize()
 
     stats_acc = []
 
-    def render_shard(prm, out):
-        stats_acc.append(ctx.render_device(scene, cam, prm, out.data_ptr()))
-
     def step():
-        if rehearsal and dist is not None:      # gloo cannot gather device tensors: stage through the host
-            def shard_to_host(prm, out):
-                t = torch.zeros(out.numel(), dtype=torch.float32, device=dev)
-                render_shard(prm, t)
-                out.copy_(t.cpu())
-            return D.render_sharded(shard_to_host, base, rank, n_gpus, dist, device="cpu")
-        return D.render_sharded(render_shard, base, rank, n_gpus, dist, device=dev)
+        if n_gpus == 1:
+            stats_acc.append(ctx.render_device(scene, cam, base, frame1.data_ptr()))
+            return frame1
+        frame, st = D.render_gathered(ctx, scene, cam, base, rank, A.RT_OUT_RGB_SUM_F32, device=dev)
+        stats_acc.append(st)
+        return frame
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step()
     stats_acc.clear()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        gathered = step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    cdev = "cpu" if rehearsal else dev
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        step()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
 
     # per-rank device statistics of the timed steps
     seg = sum(s["segments"] for s in stats_acc)
     ext_ms = sum(s["extend_ms"] for s in stats_acc)
     shade_ms = sum(s["shade_ms"] for s in stats_acc)
+    other_ms = sum(s["other_ms"] for s in stats_acc)
+    gather_ms = sum(s["gather_ms"] for s in stats_acc)
     launches = sum(s["extend_launches"] for s in stats_acc)
-    samples_rank = sum(s["samples"] for s in stats_acc)
-    if dist is not None:
-        t = torch.tensor([samples_rank], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t)
-        samples_total = float(t.item())
-    else:
-        samples_total = float(samples_rank)
+    samples_total = sum_over_ranks(float(sum(s["samples"] for s in stats_acc)))
+
+    # ---- strong-scaling leg: the SAME 4096x4096 book-1 image at every N, RGB8 out (write_color on the devices, 3 B/pixel gathered) ----
+    strong = None
+    if args.strong_spp > 0 and not args.no_variants:
+        try:
+            SW = SH = 4096
+            scam = hs.camera(SW / SH)
+            sprm = pkg.make_params(SW, SH, args.strong_spp, max_depth=50, seed=1, flags=A.RT_FLAG_TIMING)
+            if n_gpus == 1:
+                f = torch.empty((SH, SW, 3), dtype=torch.float32, device=dev)
+                f8 = torch.empty((SH, SW, 3), dtype=torch.uint8, device=dev)
+                stream.synchronize()
+
+            def sstep():
+                if n_gpus == 1:
+                    st = ctx.render_device(scene, scam, sprm, f.data_ptr())
+                    ctx.resolve_device(f.data_ptr(), SW, SH, args.strong_spp, f8.data_ptr())
+                    return st
+                return D.render_gathered(ctx, scene, scam, sprm, rank, A.RT_OUT_RGB8, device=dev)[1]
+            sstep()
+            barrier()
+            t1 = time.perf_counter()
+            sst = [sstep() for _ in range(2)]
+            barrier()
+            sdt = max_over_ranks(time.perf_counter() - t1)
+            strong = {"value": round(SW * SH * args.strong_spp * 2 / sdt / 1e6, 1), "unit": "Msamples/s", "n_gpus": n_gpus, "width": SW, "height": SH,
+                      "spp": args.strong_spp, "steps": 2, "ms_per_step": round(sdt / 2 * 1e3, 2), "output": "RGB8 frame on rank 0 (write_color per shard before the gather)",
+                      "gather_ms_rank0": round(sum(s["gather_ms"] for s in sst) / 2, 3), "scaling": "strong",
+                      "note": "same image at every N: divide by the N=1 run's figure for the speed-up (north star: >= 6x at 8 GPUs)"}
+        except Exception as e:
+            strong = {"error": repr(e)}
 
     if rank != 0:
         if dist is not None:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -159,93 +198,92 @@ def main():
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"book-1 final random-spheres scene (scene_seed 1, 484 spheres, reference-shaped BVH), {W}x{H}, {args.spp} spp, "
-                               f"depth 50, seed 1; output rgb_sum left in HBM" + (f"; {n_gpus} ranks, 32x32 tiles round-robin, one RCCL gather" if n_gpus > 1 else ""),
+                               f"depth 50, seed 1; output rgb_sum left in HBM" + (f"; {n_gpus} ranks, 32x32 tiles round-robin" if n_gpus > 1 else ""),
                    "width": W, "height": H, "spp": args.spp, "max_depth": 50, "pool_slots": stats_acc[0]["pool_slots"] if stats_acc else 0,
-                   "bvh_in_lds": stats_acc[0]["bvh_in_lds"] if stats_acc else 0},
+                   "bvh_in_lds": stats_acc[0]["bvh_in_lds"] if stats_acc else 0, "gather": gather_path,
+                   "timing": "mean over the timed steps, frame left in HBM (SURVEY 8(d) asks for the host-resident median: +1 copy of 11.5 MB, < 1 ms; DESIGN.md section 5)"},
+        "kernel_ms_per_step": {"k_extend": round(ext_ms / args.steps, 3), "k_shade": round(shade_ms / args.steps, 3), "generate+resolve": round(other_ms / args.steps, 3),
+                               "gather+untile": round(gather_ms / args.steps, 3), "launches_per_step": launches // max(1, args.steps)},
     }
 
     try:
         # ---- roofline of the dominant kernel (k_extend = BVH traversal), rank 0's launches ----
-        # algorithmic bytes per ray segment = V_n*32 + V_p*20 (node and sphere records the reference
-        # algorithm touches, counted on the device in a separate counting pass of the same workload at
-        # 1/10 spp) + 32 (ray read) + 8 (hit write).
+        # The scene (24 KB) is LDS-resident, so the traversal's node/sphere records never reach HBM: the kernel's roof is VALU
+        # issue, not HBM. achieved = VALU lane-instructions per launch / average launch duration (HIP events on the launch stream,
+        # live); lane-instructions per SEGMENT are a constant of the kernel build, taken from the committed PMC pass of this very
+        # workload (SQ_THREAD_CYCLES_VALU / segments) and valid only for the sources it was measured on (source_hash).
         cprm = pkg.make_params(W, H, max(1, args.spp // 10), max_depth=50, seed=1, flags=A.RT_FLAG_COUNTERS,
                                tile_size=32 if n_gpus > 1 else 0, shard_index=0, shard_count=n_gpus)
         tmp = torch.zeros(pkg.output_floats(cprm), dtype=torch.float32, device=dev)
+        stream.synchronize()
         cst = ctx.render_device(scene, cam, cprm, tmp.data_ptr())
         vn = cst["node_tests"] / max(1, cst["segments"])
         vp = cst["prim_tests"][0] / max(1, cst["segments"])
         seg_per_sample = cst["segments"] / max(1, cst["samples"])
         b_seg_trav = vn * NODE_BYTES + vp * SPHERE_BYTES
         b_seg = b_seg_trav + RAY_BYTES + HIT_BYTES
-        achieved = seg * b_seg / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-        # HBM traffic of k_extend proper: bytes/segment from the committed PMC passes (profiles/r01_pmc_traffic.json:
-        # rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this bench, FETCH doubled for gfx950) x the
-        # segments one launch of THIS run processed. bench.py cannot collect PMC counters on itself.
-        traffic, traffic_src, pmc = None, None, {}
+        ext_s = ext_ms * 1e-3
+        pmc, pmc_note = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            pmc = tj["kernels"]["k_extend"]
-            traffic = round(pmc["bytes_per_segment"] * seg / max(1, launches) / 1e6, 3)
-            traffic_src = (f"MB per launch = {pmc['bytes_per_segment']} B/segment (PMC: {pmc['read_bytes_per_segment']} read + "
-                           f"{pmc['write_bytes_per_segment']} written, profiles/r01_pmc_traffic.json) x segments_per_launch")
-        except Exception:
-            pass
-        # a measured HBM figure beside the spec peak: device-to-device copy of 2 GiB (read + write), best of 5
-        copy_gbs = None
-        try:
-            src = torch.empty(1 << 29, dtype=torch.float32, device=dev); dst = torch.empty_like(src)
-            dst.copy_(src); torch.cuda.synchronize()
-            best = 1e9
-            for _ in range(5):
-                t1 = time.perf_counter(); dst.copy_(src); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t1)
-            copy_gbs = round(2 * src.numel() * 4 / best / 1e9, 1)
-            del src, dst
-        except Exception:
-            pass
-        out["roofline"] = {
-            "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "measured_copy_gbs": copy_gbs,
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "MB/launch", "traffic_source": traffic_src,
-            "algorithmic_mb_per_launch": round(b_seg * seg / max(1, launches) / 1e6, 3),
-            "avg_launch_ms": round(ext_ms / max(1, launches), 4), "launches": launches, "segments_per_launch": round(seg / max(1, launches), 1),
-            "bytes_per_segment": round(b_seg, 1), "node_tests_per_segment": round(vn, 2), "sphere_tests_per_segment": round(vp, 2),
-            "segments_per_sample": round(seg_per_sample, 3),
-            "note": "achieved = algorithmic bytes (node + sphere records the reference-order traversal touches, + ray read + hit write) / k_extend "
-                    "time from HIP events. The 24 KB scene is LDS-resident, so the HBM traffic of the kernel is the ray state only (`traffic`, far "
-                    "below the algorithmic bytes) and frac > 1 says nothing about HBM: the kernel is bound by VALU issue (valu_busy ~1.0 in the "
-                    "PMC passes: SQ_INSTS_VALU x 4 cycles = every SIMD cycle of the kernel), 17 VALU per node visit at 76 % lane use (DESIGN.md section 5)",
-            "valu": {"busy": pmc.get("valu_busy"), "lane_utilisation": pmc.get("valu_lane_utilisation"),
-                     "wave_instructions_per_segment": pmc.get("valu_wave_instructions_per_segment"), "source": "profiles/r01_pmc_traffic.json"},
-            "extend_ms_per_step": round(ext_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
-            # whole-path figure in SURVEY 8(d)'s units: B_sample = sum over segments (V_n*32 + V_p*20 + 128) + 12
-            "whole_path": {"bytes_per_sample": round(seg_per_sample * (b_seg_trav + 128) + 12, 1),
-                           "achieved": round(value * 1e6 * (seg_per_sample * (b_seg_trav + 128) + 12) / 1e9 / n_gpus, 1),
-                           "frac": round(value * 1e6 * (seg_per_sample * (b_seg_trav + 128) + 12) / 1e9 / n_gpus / HBM_PEAK_GBS, 4)},
-        }
-
+            tj = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
+            if tj.get("source_hash") != B.source_hash():
+                pmc_note = f"{PMC_PROFILE} was measured on other kernel sources ({tj.get('source_hash')} != {B.source_hash()}): not used"
+            else:
+                pmc = tj["kernels"]["k_extend"]
+        except Exception as e:
+            pmc_note = f"{PMC_PROFILE}: {e!r}"
+        roof = {"bound": "valu", "kernel": "k_extend", "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s",
+                "peak_note": "256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz VALU lane-instructions/s (FP32 FMA peak 157.3 TFLOP/s = 2 flop per lane-instruction)",
+                "avg_launch_ms": round(ext_ms / max(1, launches), 4), "launches": launches, "segments_per_launch": round(seg / max(1, launches), 1),
+                "node_tests_per_segment": round(vn, 2), "sphere_tests_per_segment": round(vp, 2), "segments_per_sample": round(seg_per_sample, 3)}
+        if pmc is not None and ext_s > 0:
+            lops = pmc["valu_lane_instructions_per_segment"]
+            achieved = seg * lops / ext_s / 1e12
+            roof.update({"achieved": round(achieved, 2), "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
+                         "lane_instructions_per_segment": lops, "lane_instructions_per_launch": round(lops * seg / max(1, launches)),
+                         "traffic": round(pmc["bytes_per_segment"] * seg / max(1, launches) / 1e6, 3), "traffic_unit": "MB/launch",
+                         "traffic_source": f"{pmc['bytes_per_segment']} B/segment HBM (PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes) x segments_per_launch",
+                         "source": f"{PMC_PROFILE} (source_hash {tj['source_hash']}, git {tj.get('git_commit')})",
+                         "pmc": {k: pmc.get(k) for k in ("valu_lane_frac", "valu_issue_frac", "valu_lane_utilisation", "lds_busy", "lds_conflict_share",
+                                                         "salu_per_valu", "wait_inst_any_share", "wait_any_share")}})
+        else:
+            roof.update({"achieved": None, "frac": None, "traffic": None, "note": pmc_note})
+        # secondary: the north star's HBM view. Algorithmic bytes (node + sphere records the reference-order traversal touches, + ray
+        # read + hit write) against the HBM peak — NOT a fraction of anything the kernel is bound by: these bytes come from LDS.
+        alg_gbs = seg * b_seg / ext_s / 1e9 if ext_s > 0 else 0.0
+        roof["hbm_view"] = {"algorithmic_bytes_per_segment": round(b_seg, 1), "algorithmic_gbs": round(alg_gbs, 1),
+                            "algorithmic_over_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 3),
+                            "measured_hbm_bytes_per_segment": pmc["bytes_per_segment"] if pmc else None,
+                            "measured_hbm_gbs": round(seg * pmc["bytes_per_segment"] / ext_s / 1e9, 1) if pmc and ext_s > 0 else None,
+                            "measured_over_hbm_peak": round(seg * pmc["bytes_per_segment"] / ext_s / 1e9 / HBM_PEAK_GBS, 4) if pmc and ext_s > 0 else None,
+                            "note": "the 24 KB scene is LDS-resident: HBM sees the ray records only; the HBM roofline applies to config 5 (profiles/r02_pmc_c5.json)"}
+        out["roofline"] = roof
     except Exception as e:   # the contract line must survive a failure in the extras
-        out["roofline"] = {"bound": "hbm", "error": repr(e)}
+        out["roofline"] = {"bound": "valu", "error": repr(e)}
 
+    variants = {}
+    if strong is not None:
+        variants["strong_4096"] = strong
     # ---- same workload on the RT_BVH_SAH tree (library option, not the reference's builder): reported beside, never as `value` ----
-    if n_gpus == 1:
+    if n_gpus == 1 and not args.no_variants:
         try:
             hs2 = pkg.HostScene("book1_sah", 1)
             scene2 = ctx.upload(hs2.desc)
-            tmp2 = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
-            ctx.render_device(scene2, cam, base, tmp2.data_ptr())
+            ctx.render_device(scene2, cam, base, frame1.data_ptr())
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            s2 = ctx.render_device(scene2, cam, base, tmp2.data_ptr())
+            s2 = ctx.render_device(scene2, cam, base, frame1.data_ptr())
             torch.cuda.synchronize()
             d2 = time.perf_counter() - t1
-            out["variants"] = {"bvh_sah": {"value": round(s2["samples"] / d2 / 1e6, 1), "unit": "Msamples/s", "extend_ms": round(s2["extend_ms"], 1),
-                                           "note": "identical frame (tests/test_gpu_scenes.py::test_sah_builder_gives_the_same_picture), ~23 node tests/segment instead of 41.7"}}
+            variants["bvh_sah"] = {"value": round(s2["samples"] / d2 / 1e6, 1), "unit": "Msamples/s", "extend_ms": round(s2["extend_ms"], 1),
+                                   "note": "identical frame (tests/test_gpu_scenes.py::test_sah_builder_gives_the_same_picture), ~23 node tests/segment instead of 41.7"}
         except Exception as e:   # never let the extra line break the contract line
-            out["variants"] = {"bvh_sah": {"error": str(e)}}
+            variants["bvh_sah"] = {"error": str(e)}
+    if variants:
+        out["variants"] = variants
 
     try:
-        # ---- CPU baseline: the oracle (a port of the reference's CPU path), all host cores, bounded sample ----
+        # ---- CPU baseline: the oracle (a port of the reference's CPU path), all host cores, bounded samples ----
         if n_gpus == 1 and args.cpu_seconds > 0:
             from oracle import binding as orc
             cores = host_cores()
@@ -257,13 +295,28 @@ def main():
             spp_b = int(max(2, min(args.spp, args.cpu_seconds * rate / (bw * bh))))
             bprm = pkg.make_params(bw, bh, spp_b, max_depth=50, seed=1)
             _, bst = orc.render(hs.desc, bcam, bprm, precision=64, n_threads=cores)
-            out["cpu_baseline"] = {"value": round(bst["samples"] / bst["seconds"] / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                                   "sample": f"same scene/camera/seed at {bw}x{bh}, {spp_b} spp ({bst['samples']} samples, {bst['seconds']:.1f} s), "
-                                             f"f64 oracle (oracle/oracle.cpp), std::thread over rows"}
+            cb = {"value": round(bst["samples"] / bst["seconds"] / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                  "sample": f"same scene/camera/seed at {bw}x{bh}, {spp_b} spp ({bst['samples']} samples, {bst['seconds']:.1f} s), "
+                            f"f64 oracle (oracle/oracle.cpp), std::thread over rows"}
+            # BASELINE configs[0] in full (400x225, 100 spp: the reference's own CPU-runnable case), same port
+            c1cam = hs.camera(400 / 225)
+            c1 = pkg.make_params(400, 225, 100, max_depth=50, seed=1)
+            _, c1st = orc.render(hs.desc, c1cam, c1, precision=64, n_threads=cores)
+            cb["c1_full"] = {"value": round(c1st["samples"] / c1st["seconds"] / 1e6, 3), "unit": "Msamples/s", "seconds": round(c1st["seconds"], 2),
+                             "sample": "BASELINE configs[0] whole: 400x225, 100 spp, depth 50 (9.0 Msamples)"}
+            # the reference's own driver shape (main.rs:730-778): one pixel at a time, thread_num threads spawned per pixel
+            rows = 8
+            y0 = 225 // 2
+            _, rst = orc.render_reference_shaped(hs.desc, c1cam, c1, 20, (0, y0, 400, y0 + rows))
+            cb["reference_shaped"] = {"value": round(rst["samples"] / rst["seconds"] / 1e6, 4), "unit": "Msamples/s", "threads_per_pixel": 20,
+                                      "sample": f"configs[0], rows {y0}..{y0 + rows - 1} ({rst['samples']} samples, {rst['seconds']:.1f} s): one pixel at a time, 20 threads "
+                                                f"spawned per pixel x 5 samples each (main.rs:730-778 uses 18, which does not divide 100)"}
+            out["cpu_baseline"] = cb
     except Exception as e:
         out["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u
 
 typedef enum RtStatus {
     RT_OK = 0,
@@ -209,9 +209,13 @@ typedef struct RtStats {
     uint32_t bvh_in_lds;      /* 1 if the whole node/primitive set is staged in LDS */
     uint32_t _pad;
     uint64_t debug[8];        /* diagnostic builds only (in-kernel cycle stamps); 0 otherwise */
+    double gather_ms;         /* multi-GPU: RCCL gather + untile on the root device (HIP events on the root's stream) */
+    uint32_t n_devices;       /* GPUs that took part (1 for rt_render / rt_render_device) */
+    uint32_t lds_top_nodes;   /* node records of the top of the tree staged in LDS when the whole scene does not fit (0 otherwise) */
 } RtStats;
 
-typedef struct RtCtx RtCtx;      /* one per (process, device, stream); not re-entrant */
+typedef struct RtCtx RtCtx;      /* one per (process, device, stream); not re-entrant (one render at a time per context; distinct
+                                    contexts may be used from distinct host threads) */
 typedef struct RtScene RtScene;  /* device-resident compiled scene, owned by the library */
 
 /* Create a context on `device_id`. `stream` is a hipStream_t to launch on (so a caller such as
@@ -250,6 +254,56 @@ int rt_untile(const RtParams* params, const float* gathered, float* rgb_sum);
 /* write_color (main.rs:141-169) on the device: rgb_sum (device, full frame) -> RGB8 (device). */
 int rt_resolve_device(RtCtx* ctx, const void* rgb_sum_device, uint32_t width, uint32_t height,
                       uint32_t samples_per_pixel, void* rgb8_device);
+
+/* ---- multi-GPU: the framebuffer tile-sharded over the GPUs of one node, one RCCL gather over xGMI -----------------------
+ *
+ * The path shards by independent pixels (main.rs:731-784 carries no cross-pixel state): the image is cut into
+ * tile_size x tile_size tiles, tile t belongs to GPU t % n, the scene is replicated, every GPU renders its tiles into a compact
+ * buffer, and ONE grouped ncclSend/ncclRecv exchange moves the shards to the root, whose device puts the tiles in place. The
+ * picture does not depend on n (the RNG is keyed by the global pixel index). RCCL is loaded (dlopen librccl.so.1) at the first of
+ * these calls; the single-GPU entry points above never touch it.
+ *
+ * RT_OUT_RGB8 applies write_color (main.rs:141-169) on every shard BEFORE the gather: 3 bytes per pixel cross xGMI instead of 12. */
+typedef enum RtOutputKind {
+    RT_OUT_RGB_SUM_F32 = 0,  /* per-pixel RGB sums, f32 (what rt_render writes) */
+    RT_OUT_RGB8 = 1          /* write_color applied: RGB8, the bytes main.rs:781 stores into the image buffer */
+} RtOutputKind;
+
+/* (a) ONE PROCESS, n GPUs — what the reference's single-process host (main.rs:651-799) binds: replaces the pixel loops
+ *     main.rs:730-784 by one call. n device contexts, one host thread per device inside the call, ncclCommInitAll. */
+typedef struct RtMultiCtx RtMultiCtx;
+typedef struct RtMultiScene RtMultiScene;
+int rt_ctx_create_multi(const int* device_ids, int n_devices, RtMultiCtx** out_ctx);
+int rt_ctx_destroy_multi(RtMultiCtx* ctx);
+int rt_scene_upload_multi(RtMultiCtx* ctx, const RtSceneDesc* desc, RtMultiScene** out_scene);   /* replicated on every device */
+int rt_scene_destroy_multi(RtMultiCtx* ctx, RtMultiScene* scene);
+/* Full frame to HOST memory: rgb_sum_host[(y*width + x)*3 + c] f32 sums, or rgb8_host[...] after write_color.
+   params->shard_index / shard_count are ignored (the library shards over its devices); tile_size 0 = 32. */
+int rt_render_multi(RtMultiCtx* ctx, const RtMultiScene* scene, const RtCamera* cam, const RtParams* params,
+                    float* rgb_sum_host, RtStats* stats);
+int rt_render_multi_rgb8(RtMultiCtx* ctx, const RtMultiScene* scene, const RtCamera* cam, const RtParams* params,
+                         uint8_t* rgb8_host, RtStats* stats);
+const char* rt_last_error_multi(const RtMultiCtx* ctx);
+
+/* (b) ONE PROCESS PER GPU (torchrun-style launchers): every rank owns an RtCtx; rank 0 makes the RCCL id, the launcher's own
+ *     channel carries its 128 bytes to the other ranks, every rank attaches a communicator to its context. */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(uint8_t* id_out /* RT_COMM_ID_BYTES */);
+int rt_comm_init_rank(RtCtx* ctx, const uint8_t* id /* RT_COMM_ID_BYTES */, int rank, int world);   /* collective over all ranks */
+/* A grouped ncclSend/ncclRecv of a small buffer from this rank to itself through the context's communicator, checked byte for
+   byte: proves on a one-GPU box that librccl loads, the communicator works and the exchange completes on the context's stream. */
+int rt_comm_selftest(RtCtx* ctx);
+/* Collective: every rank renders its shard (shard_index / shard_count of `params` are ignored, the communicator's rank / world
+   are used) and sends it to rank 0; rank 0 leaves the FULL frame in `frame_device` (width*height*3 elements of f32 or u8,
+   device memory the caller owns; other ranks pass NULL). Blocks until this rank's part is done. */
+int rt_render_gather(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* params, uint32_t output_kind,
+                     void* frame_device, RtStats* stats);
+/* The root's last step on its own, for callers that gather shards themselves (e.g. with torch.distributed): `gathered_device` =
+   params->shard_count shard buffers of shard 0's size back to back (f32 rgb sums or, output_kind RT_OUT_RGB8, bytes), device memory;
+   `frame_device` = width*height*3 elements. One kernel on the context's stream; blocks until done. */
+int rt_untile_device(RtCtx* ctx, const RtParams* params, uint32_t output_kind, const void* gathered_device, void* frame_device);
+/* rt_untile for RGB8 shard buffers (host helper, same layout rules as rt_untile). */
+int rt_untile_rgb8(const RtParams* params, const uint8_t* gathered, uint8_t* rgb8);
 
 /* ---- introspection of the scene compiler: host only, never touches a GPU ---- */
 typedef struct RtCompileInfo {

@@ -52,6 +52,8 @@ def lib():
         L.orc_render_samples.argtypes = [vp, vp, vp, C.POINTER(OrcOpts), f64p, f64p, C.POINTER(OrcStats)]
         L.orc_render_crops.restype = C.c_int
         L.orc_render_crops.argtypes = [vp, vp, vp, C.POINTER(OrcOpts), C.c_int32, C.POINTER(C.c_int32), f64p, C.POINTER(OrcStats)]
+        L.orc_render_reference_shaped.restype = C.c_int
+        L.orc_render_reference_shaped.argtypes = [vp, vp, vp, C.c_int32, C.POINTER(C.c_int32), f64p, C.POINTER(OrcStats)]
         L.orc_write_color.restype = None
         L.orc_write_color.argtypes = [f64p, C.c_uint32, C.POINTER(C.c_uint8)]
         L.orc_camera_new.restype = None
@@ -125,6 +127,19 @@ def render_crops(desc, cam, params, rects, precision=64, n_threads=1, count=Fals
         crops.append(out[at:at + h * w * 3].reshape(h, w, 3).copy())
         at += h * w * 3
     return crops, [s.as_dict() for s in st]
+
+
+def render_reference_shaped(desc, cam, params, thread_num, rect):
+    """main.rs:730-778 as written (one pixel at a time, thread_num threads spawned per pixel). Returns (rgb_sum (h,w,3), stats)."""
+    L = lib()
+    x0, y0, x1, y1 = rect
+    out = np.zeros((y1 - y0, x1 - x0, 3), dtype=np.float64)
+    st = OrcStats()
+    r4 = (C.c_int32 * 4)(x0, y0, x1, y1)
+    rc = L.orc_render_reference_shaped(C.byref(desc), C.byref(cam), C.byref(params), thread_num, r4, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle: " + L.orc_last_error().decode())
+    return out, st.as_dict()
 
 
 def write_color(pixel_color, spp):

@@ -1109,6 +1109,57 @@ static int render_t(const RtSceneDesc* desc, const RtCamera* cam_d, const RtPara
     return render_rect<R>(sc, cam, prm, opt->n_threads, opt->count != 0, x0, y0, x1, y1, false, rgb_sum, st, per_sample);
 }
 
+// The reference's own driver shape, main.rs:730-778: ONE PIXEL AT A TIME, `thread_num` threads spawned per pixel, each tracing
+// spp / thread_num samples; the main thread adds the threads' samples in receiver order (thread 0's first) and joins them
+// (the reference needs thread_num | spp: assert_eq!(cnt, SAMPLES_PER_PIXEL), main.rs:779). A timing data point only: it shows
+// what the reference's threading costs beside the row-parallel port. Thread t traces samples [t*k, (t+1)*k) of the counter RNG,
+// so the pixel sums equal render_rect's up to the order of the f64 additions — which is the same order (sample 0, 1, 2, ...).
+template <class R>
+static int render_reference_shaped(const Scene<R>& sc, const Camera<R>& cam, const RtParams* prm, int thread_num, int x0, int y0, int x1, int y1,
+                                   double* rgb_sum /* compact */, OrcStats* st) {
+    const uint32_t W = prm->width, H = prm->height, spp = prm->samples_per_pixel;
+    if (thread_num < 1 || spp % (uint32_t)thread_num != 0) { g_err = "thread_num must divide samples_per_pixel (main.rs:779)"; return -1; }
+    if (x0 < 0 || y0 < 0 || x1 > (int)W || y1 > (int)H || x1 <= x0 || y1 <= y0) { g_err = "bad rectangle"; return -1; }
+    const uint32_t k = spp / (uint32_t)thread_num;
+    auto t_begin = std::chrono::steady_clock::now();
+    uint64_t samples = 0;
+    std::vector<std::vector<Vec3<R>>> received((size_t)thread_num, std::vector<Vec3<R>>(k));
+    for (int y = y0; y < y1; ++y) {                      // main.rs:731 runs j from the top row down: the same order
+        const int j = (int)H - 1 - y;
+        for (int x = x0; x < x1; ++x) {
+            const uint64_t pixel_index = (uint64_t)y * W + (uint64_t)x;
+            std::vector<std::thread> handles;
+            for (int t = 0; t < thread_num; ++t) {
+                handles.emplace_back([&, t] {              // main.rs:750 thread::spawn
+                    for (uint32_t q = 0; q < k; ++q) {
+                        const uint32_t s = (uint32_t)t * k + q;
+                        Rng<R> g; g.base = path_base(prm->seed, pixel_index, s); g.state = g.base; g.segment = 0; g.cnt = nullptr;
+                        Ctx<R> cx{&g, nullptr, 0};
+                        R ju = g.random_double(), jv = g.random_double();
+                        R u = ((R)x + ju) / (R)(W - 1), v = ((R)j + jv) / (R)(H - 1);
+                        Ray<R> r = cam.get_ray(u, v, g);
+                        received[(size_t)t][q] = ray_color(r, sc, (int)prm->max_depth, cx);   // tx.send(...)
+                    }
+                });
+            }
+            for (auto& h : handles) h.join();                // the channels are drained in receiver order below (main.rs:769-775)
+            double sum[3] = {0, 0, 0};
+            for (int t = 0; t < thread_num; ++t)
+                for (uint32_t q = 0; q < k; ++q) {
+                    double cd[3] = {(double)received[(size_t)t][q].e[0], (double)received[(size_t)t][q].e[1], (double)received[(size_t)t][q].e[2]};
+                    const bool finite = std::isfinite(cd[0]) && std::isfinite(cd[1]) && std::isfinite(cd[2]);
+                    if (!finite && prm->nan_policy == RT_NAN_PER_SAMPLE) cd[0] = cd[1] = cd[2] = 0.0;
+                    sum[0] += cd[0]; sum[1] += cd[1]; sum[2] += cd[2];
+                    ++samples;
+                }
+            double* o = rgb_sum + ((size_t)(y - y0) * (size_t)(x1 - x0) + (size_t)(x - x0)) * 3;
+            o[0] = sum[0]; o[1] = sum[1]; o[2] = sum[2];
+        }
+    }
+    if (st) { std::memset(st, 0, sizeof(*st)); st->samples = samples; st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); }
+    return 0;
+}
+
 // Several rectangles of one frame with ONE scene build (the 1 M-primitive scene of BASELINE config 5 takes seconds to
 // build): rects = n x (x0, y0, x1, y1); out = the rectangles back to back, compact; stats[n] = counters per rectangle.
 template <class R>
@@ -1151,6 +1202,16 @@ int orc_render_crops(const RtSceneDesc* desc, const RtCamera* cam, const RtParam
     if (!desc || !cam || !prm || !opt || !rects || !out || n_rects <= 0) { g_err = "null argument"; return -1; }
     if (opt->precision == 32) return orc::render_crops_t<float>(desc, cam, prm, opt, n_rects, rects, out, stats);
     return orc::render_crops_t<double>(desc, cam, prm, opt, n_rects, rects, out, stats);
+}
+
+/* main.rs:730-778 as written: one pixel at a time, thread_num threads per pixel (f64). out = the rectangle, compact. */
+int orc_render_reference_shaped(const RtSceneDesc* desc, const RtCamera* cam, const RtParams* prm, int32_t thread_num, const int32_t* rect4, double* out,
+                                OrcStats* st) {
+    if (!desc || !cam || !prm || !rect4 || !out) { g_err = "null argument"; return -1; }
+    orc::Scene<double> sc;
+    if (!sc.load(*desc)) { g_err = "scene: " + sc.error; return -1; }
+    const orc::Camera<double> c = orc::camera_from<double>(cam);
+    return orc::render_reference_shaped<double>(sc, c, prm, thread_num, rect4[0], rect4[1], rect4[2], rect4[3], out, st);
 }
 
 void orc_write_color(const double* pixel_color, uint32_t samples_per_pixel, uint8_t* out3) { orc::write_color(pixel_color, samples_per_pixel, out3); }

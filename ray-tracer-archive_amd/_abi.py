@@ -1,7 +1,7 @@
 """ctypes mirror of include/rt_hip.h and include/rt_host.h (struct layouts must match the headers)."""
 import ctypes as C
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_N_PRIM_TYPES = 6
 
 RT_OK, RT_ERR_INVALID, RT_ERR_UNSUPPORTED, RT_ERR_DEVICE, RT_ERR_NO_DEVICE, RT_ERR_OOM = 0, -1, -2, -3, -4, -5
@@ -14,6 +14,8 @@ RT_BG_CONSTANT, RT_BG_SKY_GRADIENT = 0, 1
 RT_BVH_REFERENCE, RT_BVH_SAH = 0, 1
 RT_NAN_PER_SAMPLE, RT_NAN_REFERENCE = 0, 1
 RT_FLAG_COUNTERS, RT_FLAG_TIMING, RT_FLAG_SAMPLE_BLOCKS = 1, 2, 4
+RT_OUT_RGB_SUM_F32, RT_OUT_RGB8 = 0, 1
+RT_COMM_ID_BYTES = 128
 
 
 class RtVec3(C.Structure):
@@ -70,7 +72,8 @@ class RtStats(C.Structure):
     _fields_ = [("render_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("other_ms", C.c_double),
                 ("samples", C.c_uint64), ("segments", C.c_uint64), ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64 * RT_N_PRIM_TYPES),
                 ("iterations", C.c_uint32), ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("pool_slots", C.c_uint32),
-                ("scene_nodes", C.c_uint64), ("scene_prims", C.c_uint64), ("scene_bytes", C.c_uint64), ("bvh_in_lds", C.c_uint32), ("_pad", C.c_uint32), ("debug", C.c_uint64 * 8)]
+                ("scene_nodes", C.c_uint64), ("scene_prims", C.c_uint64), ("scene_bytes", C.c_uint64), ("bvh_in_lds", C.c_uint32), ("_pad", C.c_uint32), ("debug", C.c_uint64 * 8),
+                ("gather_ms", C.c_double), ("n_devices", C.c_uint32), ("lds_top_nodes", C.c_uint32)]
 
     def as_dict(self):
         d = {}
@@ -91,7 +94,9 @@ class RtCompileInfo(C.Structure):
 # every symbol include/rt_hip.h and include/rt_host.h declare
 RT_HIP_SYMBOLS = ["rt_ctx_create", "rt_ctx_destroy", "rt_scene_upload", "rt_scene_destroy", "rt_output_floats", "rt_render",
                   "rt_render_device", "rt_untile", "rt_resolve_device", "rt_last_error", "rt_abi_version", "rt_scene_compile_info",
-                  "rt_scene_compile_dump"]
+                  "rt_scene_compile_dump", "rt_ctx_create_multi", "rt_ctx_destroy_multi", "rt_scene_upload_multi", "rt_scene_destroy_multi",
+                  "rt_render_multi", "rt_render_multi_rgb8", "rt_last_error_multi", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_selftest",
+                  "rt_render_gather", "rt_untile_rgb8", "rt_untile_device"]
 RT_HOST_SYMBOLS = ["rt_host_scene_create", "rt_host_scene_desc", "rt_host_scene_camera", "rt_host_scene_destroy", "rt_host_camera_new",
                    "rt_host_write_color", "rt_host_tonemap", "rt_host_write_png"]
 
@@ -126,6 +131,32 @@ def declare(lib):
     lib.rt_scene_compile_info.argtypes = [P(RtSceneDesc), P(RtCompileInfo)]
     lib.rt_scene_compile_dump.restype = i32
     lib.rt_scene_compile_dump.argtypes = [P(RtSceneDesc), vp, u64, P(C.c_float), P(u32), u64]
+    lib.rt_untile_rgb8.restype = i32
+    lib.rt_untile_rgb8.argtypes = [P(RtParams), P(C.c_uint8), P(C.c_uint8)]
+    lib.rt_ctx_create_multi.restype = i32
+    lib.rt_ctx_create_multi.argtypes = [P(C.c_int), i32, P(vp)]
+    lib.rt_ctx_destroy_multi.restype = i32
+    lib.rt_ctx_destroy_multi.argtypes = [vp]
+    lib.rt_scene_upload_multi.restype = i32
+    lib.rt_scene_upload_multi.argtypes = [vp, P(RtSceneDesc), P(vp)]
+    lib.rt_scene_destroy_multi.restype = i32
+    lib.rt_scene_destroy_multi.argtypes = [vp, vp]
+    lib.rt_render_multi.restype = i32
+    lib.rt_render_multi.argtypes = [vp, vp, P(RtCamera), P(RtParams), P(C.c_float), P(RtStats)]
+    lib.rt_render_multi_rgb8.restype = i32
+    lib.rt_render_multi_rgb8.argtypes = [vp, vp, P(RtCamera), P(RtParams), P(C.c_uint8), P(RtStats)]
+    lib.rt_last_error_multi.restype = C.c_char_p
+    lib.rt_last_error_multi.argtypes = [vp]
+    lib.rt_comm_unique_id.restype = i32
+    lib.rt_comm_unique_id.argtypes = [P(C.c_uint8)]
+    lib.rt_comm_init_rank.restype = i32
+    lib.rt_comm_init_rank.argtypes = [vp, P(C.c_uint8), i32, i32]
+    lib.rt_comm_selftest.restype = i32
+    lib.rt_comm_selftest.argtypes = [vp]
+    lib.rt_render_gather.restype = i32
+    lib.rt_render_gather.argtypes = [vp, vp, P(RtCamera), P(RtParams), u32, vp, P(RtStats)]
+    lib.rt_untile_device.restype = i32
+    lib.rt_untile_device.argtypes = [vp, P(RtParams), u32, vp, vp]
     lib.rt_host_scene_create.restype = i32
     lib.rt_host_scene_create.argtypes = [C.c_char_p, u64, u64, u64, P(C.c_uint8), u32, u32, P(vp)]
     lib.rt_host_scene_desc.restype = P(RtSceneDesc)

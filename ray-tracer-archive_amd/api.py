@@ -91,6 +91,20 @@ def untile(params, gathered):
     return out
 
 
+def untile_rgb8(params, gathered):
+    gathered = np.ascontiguousarray(gathered, dtype=np.uint8)
+    out = np.zeros((params.height, params.width, 3), dtype=np.uint8)
+    _check(lib().rt_untile_rgb8(C.byref(params), gathered.ctypes.data_as(C.POINTER(C.c_uint8)), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out
+
+
+def comm_unique_id():
+    """rt_comm_unique_id: the 128 bytes rank 0 hands to every other rank (over the launcher's own channel)."""
+    buf = (C.c_uint8 * A.RT_COMM_ID_BYTES)()
+    _check(lib().rt_comm_unique_id(buf))
+    return bytes(buf)
+
+
 def compile_info(desc):
     """rt_scene_compile_info: what the scene compiler makes of a graph (host only)."""
     info = A.RtCompileInfo()
@@ -190,12 +204,90 @@ class Context:
         _check(lib().rt_render_device(self._h, scene._h, C.byref(cam), C.byref(params), C.c_void_p(device_ptr), C.byref(st)), self._h)
         return st.as_dict()
 
+    # ---- one process per GPU: RCCL communicator on this context (rt_multi.cpp) ----
+    def comm_init_rank(self, unique_id, rank, world):
+        buf = (C.c_uint8 * A.RT_COMM_ID_BYTES)(*unique_id)
+        _check(lib().rt_comm_init_rank(self._h, buf, rank, world), self._h)
+
+    def comm_selftest(self):
+        _check(lib().rt_comm_selftest(self._h), self._h)
+
+    def render_gather(self, scene, cam, params, output_kind=A.RT_OUT_RGB_SUM_F32, frame_ptr=None):
+        """rt_render_gather (collective): this rank's shard is rendered and sent to rank 0, which leaves the full frame at frame_ptr."""
+        st = A.RtStats()
+        _check(lib().rt_render_gather(self._h, scene._h, C.byref(cam), C.byref(params), output_kind, C.c_void_p(frame_ptr) if frame_ptr else None, C.byref(st)),
+               self._h)
+        return st.as_dict()
+
+    def untile_device(self, params, output_kind, gathered_ptr, frame_ptr):
+        _check(lib().rt_untile_device(self._h, C.byref(params), output_kind, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr)), self._h)
+
     def resolve_device(self, rgb_sum_ptr, width, height, spp, rgb8_ptr):
         _check(lib().rt_resolve_device(self._h, C.c_void_p(rgb_sum_ptr), width, height, spp, C.c_void_p(rgb8_ptr)), self._h)
 
     def close(self):
         if self._h:
             lib().rt_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiScene:
+    def __init__(self, mctx, desc):
+        self.mctx = mctx
+        self._h = C.c_void_p()
+        code = lib().rt_scene_upload_multi(mctx._h, C.byref(desc), C.byref(self._h))
+        if code != A.RT_OK:
+            raise RtError(code, lib().rt_last_error_multi(mctx._h).decode())
+
+    def close(self):
+        if self._h and self.mctx._h:
+            lib().rt_scene_destroy_multi(self.mctx._h, self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiContext:
+    """rt_ctx_create_multi: ONE process driving n GPUs (what the reference's single-process host binds). The framebuffer is
+    tile-sharded over the devices and gathered on the first one with RCCL inside rt_render_multi."""
+
+    def __init__(self, device_ids):
+        self._h = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        _check(lib().rt_ctx_create_multi(ids, len(device_ids), C.byref(self._h)))
+        self.n = len(device_ids)
+
+    def upload(self, desc):
+        return MultiScene(self, desc)
+
+    def _render(self, fn, scene, cam, params, out, ptr_t):
+        st = A.RtStats()
+        code = fn(self._h, scene._h, C.byref(cam), C.byref(params), out.ctypes.data_as(C.POINTER(ptr_t)), C.byref(st))
+        if code != A.RT_OK:
+            raise RtError(code, lib().rt_last_error_multi(self._h).decode())
+        return out, st.as_dict()
+
+    def render(self, scene, cam, params):
+        """rt_render_multi: full frame of f32 RGB sums on the host."""
+        return self._render(lib().rt_render_multi, scene, cam, params, np.empty((params.height, params.width, 3), dtype=np.float32), C.c_float)
+
+    def render_rgb8(self, scene, cam, params):
+        """rt_render_multi_rgb8: write_color applied per shard on the devices, RGB8 gathered (3 B/pixel over xGMI)."""
+        return self._render(lib().rt_render_multi_rgb8, scene, cam, params, np.empty((params.height, params.width, 3), dtype=np.uint8), C.c_uint8)
+
+    def close(self):
+        if self._h:
+            lib().rt_ctx_destroy_multi(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -6,8 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librt_hip.so")
-SOURCES = ["csrc/kernels.hip", "csrc/rt_api.cpp", "csrc/scene_compile.cpp", "host/host_capi.cpp"]
-HEADERS = ["csrc/kernels.h", "csrc/device_types.h", "csrc/scene_compile.hpp", "host/rt_host.hpp", "../include/rt_hip.h", "../include/rt_host.h"]
+SOURCES = ["csrc/kernels.hip", "csrc/rt_api.cpp", "csrc/rt_multi.cpp", "csrc/scene_compile.cpp", "host/host_capi.cpp"]
+HEADERS = ["csrc/kernels.h", "csrc/device_types.h", "csrc/rt_internal.hpp", "csrc/scene_compile.hpp", "host/rt_host.hpp", "../include/rt_hip.h", "../include/rt_host.h"]
 # -ffp-contract=off: a float expression means the same IEEE operations wherever it is inlined, so a
 # sample's radiance does not depend on which kernel / call site generated its camera ray (and the
 # device evaluates the reference's expressions in the order written). Hot loops spell out fmaf/fma.
@@ -15,6 +15,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wal
          # every atomic here is already one-per-wave / one-per-workgroup; LLVM's wave-aggregation pass would only add a
          # readfirstlane that forces an immediate wait on the returning atomic (k_extend grabs its chunk one ahead)
          "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+
+
+def source_hash():
+    """sha256 over the device-side sources: what a PMC profile under profiles/ is valid for (bench.py refuses a profile taken
+    from other kernels)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ["csrc/kernels.hip", "csrc/kernels.h", "csrc/device_types.h"]:
+        h.update(open(os.path.join(HERE, f), "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
 
 
 def needs_build():
@@ -30,7 +41,7 @@ def build_variant(name, defines, verbose=False):
     vdir = os.path.join(LIB_DIR, "variants")
     os.makedirs(vdir, exist_ok=True)
     out = os.path.join(vdir, f"librt_hip_{name}.so")
-    cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + SOURCES + ["-lz"]
+    cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + SOURCES + ["-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
@@ -47,7 +58,7 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build the HIP library")
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + FLAGS + ["-o", LIB_PATH] + SOURCES + ["-lz"]
+    cmd = [hipcc] + FLAGS + ["-o", LIB_PATH] + SOURCES + ["-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)

@@ -93,5 +93,10 @@ hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev&
                         bool count, hipStream_t stream);
 hipError_t launch_resolve(const RenderDev& rd, float* out, uint32_t n_valid_pixels, hipStream_t stream);
 hipError_t launch_write_color(const float* rgb_sum, uint32_t n_pixels, uint32_t spp, uint8_t* rgb8, hipStream_t stream);
+// multi-GPU root: gathered shard buffers -> full frame (rt_multi.cpp)
+hipError_t launch_untile_f32(const float* gathered, float* frame, uint32_t width, uint32_t height, uint32_t ts, uint32_t tiles_x, uint32_t world, uint64_t per_shard,
+                             hipStream_t stream);
+hipError_t launch_untile_u8(const uint8_t* gathered, uint8_t* frame, uint32_t width, uint32_t height, uint32_t ts, uint32_t tiles_x, uint32_t world, uint64_t per_shard,
+                            hipStream_t stream);
 
 }  // namespace rtk

@@ -1192,6 +1192,20 @@ __global__ void __launch_bounds__(256) k_write_color(const float* __restrict__ r
     rgb8[i] = q != q ? (uint8_t)0 : (uint8_t)q;   // Rust `as u8`: saturating, NaN -> 0
 }
 
+// Gathered shard buffers (shard s = tiles s, s + world, ...; each tile ts*ts pixels row-major, shards `per_shard` elements apart)
+// -> the full frame, on the root device of a multi-GPU render. One thread per pixel; T = float (rgb sums) or uint8_t (RGB8).
+template <class T>
+__global__ void __launch_bounds__(256) k_untile(const T* __restrict__ gathered, T* __restrict__ frame, uint32_t width, uint32_t height, uint32_t ts, uint32_t tiles_x,
+                                                uint32_t world, uint64_t per_shard) {
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    const uint32_t tx = x / ts, ty = y / ts, tile = ty * tiles_x + tx;
+    const uint32_t s = tile % world, lt = tile / world;
+    const T* src = gathered + (uint64_t)s * per_shard + ((uint64_t)lt * ts * ts + (uint64_t)(y - ty * ts) * ts + (x - tx * ts)) * 3u;
+    T* dst = frame + ((uint64_t)y * width + x) * 3u;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -1290,6 +1304,17 @@ hipError_t launch_write_color(const float* rgb_sum, uint32_t n_pixels, uint32_t 
     const uint32_t blocks = (n_pixels * 3u + 255u) / 256u;
     if (blocks == 0u) return hipSuccess;
     hipLaunchKernelGGL(k_write_color, dim3(blocks), dim3(256), 0, stream, rgb_sum, n_pixels, spp, rgb8);
+    return hipGetLastError();
+}
+
+hipError_t launch_untile_f32(const float* gathered, float* frame, uint32_t width, uint32_t height, uint32_t ts, uint32_t tiles_x, uint32_t world, uint64_t per_shard,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(k_untile<float>, dim3((width + 63u) / 64u, (height + 3u) / 4u), dim3(256), 0, stream, gathered, frame, width, height, ts, tiles_x, world, per_shard);
+    return hipGetLastError();
+}
+hipError_t launch_untile_u8(const uint8_t* gathered, uint8_t* frame, uint32_t width, uint32_t height, uint32_t ts, uint32_t tiles_x, uint32_t world, uint64_t per_shard,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(k_untile<uint8_t>, dim3((width + 63u) / 64u, (height + 3u) / 4u), dim3(256), 0, stream, gathered, frame, width, height, ts, tiles_x, world, per_shard);
     return hipGetLastError();
 }
 

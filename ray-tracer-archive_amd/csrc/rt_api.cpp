@@ -12,67 +12,17 @@
 #include <limits>
 #include <vector>
 
-#include "../../include/rt_hip.h"
-#include "kernels.h"
+#include "rt_internal.hpp"
 #include "scene_compile.hpp"
 
+using namespace rti;
+
+namespace rti { thread_local std::string g_last_error; }
+
 namespace {
 
-thread_local std::string g_last_error;
 constexpr uint64_t kMaxItems = (1ull << 32) - (1ull << 28);   // work items of one render (u32 index, with head room for the allocator's overshoot)
 constexpr size_t kLdsSceneBudget = 64 * 1024;   // nodes + sphere records staged per workgroup
-
-struct DevBuf {
-    void* p = nullptr; size_t bytes = 0;
-    hipError_t ensure(size_t n) {
-        if (n <= bytes && p) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        n = std::max<size_t>(n, 256);
-        hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-};
-
-}  // namespace
-
-static uint32_t scene_features(const rtc::CompiledScene& cs);
-
-struct RtCtx {
-    int device = 0;
-    hipStream_t stream = nullptr; bool own_stream = false;
-    int n_cu = 256;
-    std::string err;
-    // grow-only work buffers
-    DevBuf pool[2][6]; DevBuf blocksum; DevBuf counters; DevBuf out_tmp; DevBuf tile_prefix;
-    uint32_t* h_count = nullptr;                 // pinned
-    unsigned long long* h_counters = nullptr;    // pinned
-    std::vector<hipEvent_t> events;
-};
-
-struct RtScene {
-    DevBuf nodes, spheres, sphere_meta, moving, moving_meta, rects, rect_meta, tris, tri_meta, media, xforms, wraps, mat_a, mat_b, textures, perlins, images,
-        image_bytes, lights;
-    rtk::SceneDev dev{};
-    uint32_t features = 0; bool in_lds = false;
-    int bg_mode = 0; float bg[3] = {0, 0, 0};
-    uint64_t n_nodes = 0, n_prims = 0, bytes = 0, lds_bytes = 0;
-};
-
-namespace {
-
-int set_err(RtCtx* ctx, int code, const std::string& msg) {
-    g_last_error = msg;
-    if (ctx) ctx->err = msg;
-    return code;
-}
-#define HIP_TRY(ctx, call)                                                                                        \
-    do {                                                                                                          \
-        hipError_t e_ = (call);                                                                                   \
-        if (e_ != hipSuccess) return set_err(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_DEVICE,          \
-                                             std::string(#call) + ": " + hipGetErrorString(e_));                  \
-    } while (0)
 
 template <class T> int upload(RtCtx* ctx, DevBuf& b, const std::vector<T>& v) {
     HIP_TRY(ctx, b.ensure(v.size() * sizeof(T)));
@@ -80,19 +30,11 @@ template <class T> int upload(RtCtx* ctx, DevBuf& b, const std::vector<T>& v) {
     return RT_OK;
 }
 
-struct Tiling { uint32_t ts, tiles_x, tiles_y, n_tiles, n_local; };
-int make_tiling(const RtParams& p, Tiling& t) {
-    t.ts = p.tile_size ? p.tile_size : 32u;
-    if (t.ts < 8u || t.ts > 256u || (t.ts & 7u)) return RT_ERR_INVALID;
-    t.tiles_x = (p.width + t.ts - 1) / t.ts; t.tiles_y = (p.height + t.ts - 1) / t.ts;
-    t.n_tiles = t.tiles_x * t.tiles_y;
-    const uint32_t sc = p.shard_count <= 1u ? 1u : p.shard_count, si = p.shard_count <= 1u ? 0u : p.shard_index;
-    if (si >= sc) return RT_ERR_INVALID;
-    t.n_local = t.n_tiles > si ? (t.n_tiles - si + sc - 1) / sc : 0u;
-    return RT_OK;
-}
+}  // namespace
 
-int validate_params(RtCtx* ctx, const RtParams* p) {
+static uint32_t scene_features(const rtc::CompiledScene& cs);
+
+int rti::validate_params(RtCtx* ctx, const RtParams* p) {
     if (!p) return set_err(ctx, RT_ERR_INVALID, "params is null");
     if (p->width < 2 || p->height < 2) return set_err(ctx, RT_ERR_INVALID, "width and height must be >= 2 (u = (i+rnd)/(W-1), main.rs:752)");
     if (p->width > 65536 || p->height > 65536) return set_err(ctx, RT_ERR_INVALID, "image too large");
@@ -104,8 +46,40 @@ int validate_params(RtCtx* ctx, const RtParams* p) {
     return RT_OK;
 }
 
-}  // namespace
+static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, void* d_out, RtStats* stats);
 
+// A render that fails half way (a HIP error, out of memory) must not leave work or recorded events in flight on the
+// caller's stream: drain it before the error goes back.
+int rti::render_checked(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, void* d_out, RtStats* stats) {
+    const int r = render_impl(ctx, scene, cam, prm, d_out, stats);
+    if (r != RT_OK) { const std::string keep = ctx->err; (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); ctx->err = keep; g_last_error = keep; }
+    return r;
+}
+
+template <class T>
+static int untile_host(const RtParams* p, const T* gathered, T* frame) {
+    if (!p || !gathered || !frame) return set_err(nullptr, RT_ERR_INVALID, "null argument");
+    Tiling t; RtParams q = *p; q.shard_count = 1; q.shard_index = 0;
+    if (make_tiling(q, t) != RT_OK) return set_err(nullptr, RT_ERR_INVALID, "bad tiling parameters");
+    const uint32_t sc = p->shard_count <= 1u ? 1u : p->shard_count;
+    const uint64_t ts2 = (uint64_t)t.ts * t.ts;
+    // every shard buffer has the size of the largest shard (shard 0)
+    const uint64_t per_shard = (uint64_t)((t.n_tiles + sc - 1) / sc) * ts2 * 3u;
+    for (uint32_t tile = 0; tile < t.n_tiles; ++tile) {
+        const uint32_t s = tile % sc, lt = tile / sc, tx = tile % t.tiles_x, ty = tile / t.tiles_x;
+        const T* src = gathered + (uint64_t)s * per_shard + (uint64_t)lt * ts2 * 3u;
+        for (uint32_t py = 0; py < t.ts; ++py) {
+            const uint32_t y = ty * t.ts + py; if (y >= p->height) break;
+            for (uint32_t px = 0; px < t.ts; ++px) {
+                const uint32_t x = tx * t.ts + px; if (x >= p->width) break;
+                const T* a = src + ((uint64_t)py * t.ts + px) * 3u;
+                T* b = frame + ((uint64_t)y * p->width + x) * 3u;
+                b[0] = a[0]; b[1] = a[1]; b[2] = a[2];
+            }
+        }
+    }
+    return RT_OK;
+}
 static int ctx_init(RtCtx* ctx, void* stream) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipDeviceProp_t prop;
@@ -142,7 +116,8 @@ int rt_ctx_destroy(RtCtx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& pl : ctx->pool) for (auto& b : pl) b.release();
-    ctx->blocksum.release(); ctx->counters.release(); ctx->out_tmp.release(); ctx->tile_prefix.release();
+    comm_release(ctx);
+    ctx->blocksum.release(); ctx->counters.release(); ctx->out_tmp.release(); ctx->tile_prefix.release(); ctx->shard_tmp.release();
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     if (ctx->h_count) (void)hipHostFree(ctx->h_count);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
@@ -232,7 +207,7 @@ int rt_scene_destroy(RtCtx* ctx, RtScene* s) {
     if (!s) return RT_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     DevBuf* all[] = {&s->nodes, &s->spheres, &s->sphere_meta, &s->moving, &s->moving_meta, &s->rects, &s->rect_meta, &s->tris, &s->tri_meta, &s->media,
-                     &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights};
+                     &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights, &s->top_nodes};
     for (DevBuf* b : all) b->release();
     delete s;
     return RT_OK;
@@ -403,17 +378,10 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         for (int k = 0; k < 5; ++k) stats->debug[k] = ctx->h_counters[rtk::CTR_DEBUG + k];
         stats->debug[6] = extend_geometry[0]; stats->debug[7] = extend_geometry[1];   // resident k_extend groups per CU (256 / 512 threads)
         stats->iterations = (uint32_t)ctx->h_counters[rtk::CTR_ITERATIONS]; stats->extend_launches = launched; stats->shade_launches = launched; stats->pool_slots = P;
+        stats->n_devices = 1u;
         stats->scene_nodes = scene->n_nodes; stats->scene_prims = scene->n_prims; stats->scene_bytes = scene->bytes; stats->bvh_in_lds = scene->in_lds ? 1u : 0u;
     }
     return RT_OK;
-}
-
-// A render that fails half way (a HIP error, out of memory) must not leave work or recorded events in flight on the
-// caller's stream: drain it before the error goes back.
-static int render_checked(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, void* d_out, RtStats* stats) {
-    const int r = render_impl(ctx, scene, cam, prm, d_out, stats);
-    if (r != RT_OK) { const std::string keep = ctx->err; (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); ctx->err = keep; g_last_error = keep; }
-    return r;
 }
 
 int rt_render_device(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, void* rgb_sum_device, RtStats* stats) {
@@ -439,29 +407,8 @@ int rt_render(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtPar
     return RT_OK;
 }
 
-int rt_untile(const RtParams* p, const float* gathered, float* rgb_sum) {
-    if (!p || !gathered || !rgb_sum) return set_err(nullptr, RT_ERR_INVALID, "null argument");
-    Tiling t; RtParams q = *p; q.shard_count = 1; q.shard_index = 0;
-    if (make_tiling(q, t) != RT_OK) return set_err(nullptr, RT_ERR_INVALID, "bad tiling parameters");
-    const uint32_t sc = p->shard_count <= 1u ? 1u : p->shard_count;
-    const uint64_t ts2 = (uint64_t)t.ts * t.ts;
-    // every shard buffer has the size of the largest shard (shard 0)
-    const uint64_t per_shard = (uint64_t)((t.n_tiles + sc - 1) / sc) * ts2 * 3u;
-    for (uint32_t tile = 0; tile < t.n_tiles; ++tile) {
-        const uint32_t s = tile % sc, lt = tile / sc, tx = tile % t.tiles_x, ty = tile / t.tiles_x;
-        const float* src = gathered + (uint64_t)s * per_shard + (uint64_t)lt * ts2 * 3u;
-        for (uint32_t py = 0; py < t.ts; ++py) {
-            const uint32_t y = ty * t.ts + py; if (y >= p->height) break;
-            for (uint32_t px = 0; px < t.ts; ++px) {
-                const uint32_t x = tx * t.ts + px; if (x >= p->width) break;
-                const float* a = src + ((uint64_t)py * t.ts + px) * 3u;
-                float* b = rgb_sum + ((uint64_t)y * p->width + x) * 3u;
-                b[0] = a[0]; b[1] = a[1]; b[2] = a[2];
-            }
-        }
-    }
-    return RT_OK;
-}
+int rt_untile(const RtParams* p, const float* gathered, float* rgb_sum) { return untile_host<float>(p, gathered, rgb_sum); }
+int rt_untile_rgb8(const RtParams* p, const uint8_t* gathered, uint8_t* rgb8) { return untile_host<uint8_t>(p, gathered, rgb8); }
 
 static uint32_t scene_features(const rtc::CompiledScene& cs) {
     uint32_t f = 0;

@@ -1,0 +1,353 @@
+// rt_multi.cpp — multi-GPU entry points of include/rt_hip.h: the framebuffer tile-sharded over the GPUs of one node and
+// gathered on the root with ONE grouped ncclSend/ncclRecv exchange (RCCL over xGMI), then put in place by a kernel on the root.
+//
+// Replaces the reference's pixel loops main.rs:730-784 for a whole node. The path has no other exchange step: pixels are
+// independent and the scene is replicated, so there is no data-path collective besides this gather. xGMI is point to point
+// (each peer has its own link to the root), so the exchange is n-1 direct sends, not a ring; with RT_OUT_RGB8 the shards are
+// tone-mapped (write_color, main.rs:141-169) before they travel: 3 bytes per pixel instead of 12.
+//
+// RCCL is loaded with dlopen at the first multi-GPU call (librccl.so.1 is a 570 MB library the single-GPU path never needs; a
+// process that already holds it — PyTorch does — shares that copy).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "rt_internal.hpp"
+
+using namespace rti;
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+const Rccl* rccl() {
+    std::call_once(g_rccl_once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.handle) break; }
+        if (!g_rccl.handle) { g_rccl.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(g_rccl.handle, n); if (!p && g_rccl.error.empty()) g_rccl.error = std::string("librccl lacks ") + n; return p; };
+        g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+        g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+        g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+        g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+        g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+        g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+        g_rccl.Send = (decltype(g_rccl.Send))sym("ncclSend");
+        g_rccl.Recv = (decltype(g_rccl.Recv))sym("ncclRecv");
+        g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    });
+    return g_rccl.error.empty() ? &g_rccl : nullptr;
+}
+#define NCCL_TRY(ctx, call)                                                                                            \
+    do {                                                                                                               \
+        ncclResult_t r_ = (call);                                                                                      \
+        if (r_ != ncclSuccess) return set_err(ctx, RT_ERR_DEVICE, std::string(#call) + ": " + R->GetErrorString(r_));  \
+    } while (0)
+
+static_assert(RT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "RT_COMM_ID_BYTES is the size of an ncclUniqueId");
+
+struct ShardGeom { Tiling tl; uint64_t per_shard_px; };   // tiles of shard 0 (the largest) * ts^2
+int shard_geom(const RtParams& prm, uint32_t world, ShardGeom& g) {
+    RtParams q = prm; q.shard_index = 0; q.shard_count = world;
+    if (make_tiling(q, g.tl) != RT_OK) return RT_ERR_INVALID;
+    g.per_shard_px = (uint64_t)g.tl.n_local * g.tl.ts * g.tl.ts;
+    return RT_OK;
+}
+
+// One rank's part of a sharded render: render shard `rank` of `world`, optional write_color on the shard, exchange, and on the
+// root the untile kernel into `frame_device`. The same code serves one-process-per-GPU (rt_render_gather) and the threads of
+// rt_render_multi (one communicator per device from ncclCommInitAll).
+int render_gather_rank(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm_in, uint32_t kind, void* frame_device, RtStats* stats) {
+    const Rccl* R = nullptr;
+    const int world = ctx->comm_world, rank = ctx->comm_rank;
+    if (world > 1) {
+        R = rccl();
+        if (!R) return set_err(ctx, RT_ERR_DEVICE, g_rccl.error);
+        if (!ctx->comm) return set_err(ctx, RT_ERR_INVALID, "no communicator on this context (rt_comm_init_rank)");
+    }
+    if (kind > RT_OUT_RGB8) return set_err(ctx, RT_ERR_INVALID, "bad output kind");
+    RtParams prm = *prm_in;
+    prm.shard_index = (uint32_t)rank; prm.shard_count = (uint32_t)world;
+    if (prm.tile_size == 0) prm.tile_size = 32;
+    const int v = validate_params(ctx, &prm); if (v != RT_OK) return v;
+    if (rank == 0 && !frame_device) return set_err(ctx, RT_ERR_INVALID, "rank 0 needs a frame buffer");
+    ShardGeom g; if (shard_geom(prm, (uint32_t)world, g) != RT_OK) return set_err(ctx, RT_ERR_INVALID, "bad tiling parameters");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t elem = kind == RT_OUT_RGB8 ? 1 : 4;
+    const size_t shard_elems = (size_t)g.per_shard_px * 3;
+    const auto t0 = std::chrono::steady_clock::now();
+    // f32 shard of this rank; the root's lives at slot 0 of the gather buffer when the exchange is f32
+    HIP_TRY(ctx, ctx->shard_tmp.ensure(shard_elems * 4 + (kind == RT_OUT_RGB8 ? shard_elems : 0)));
+    float* shard_f32 = (float*)ctx->shard_tmp.p;
+    uint8_t* shard_u8 = (uint8_t*)ctx->shard_tmp.p + shard_elems * 4;
+    void* gather = nullptr;
+    if (rank == 0 && world > 1) { HIP_TRY(ctx, ctx->out_tmp.ensure(shard_elems * elem * (size_t)world)); gather = ctx->out_tmp.p; }
+    void* mine = shard_f32;                                      // what this rank contributes, in the exchange's element type
+    if (world == 1) {
+        // one GPU: no tiles to move. f32: render straight into the caller's frame; u8: render, then write_color into it
+        prm.shard_count = 1; prm.shard_index = 0;
+        if (kind == RT_OUT_RGB_SUM_F32) return render_checked(ctx, scene, cam, &prm, frame_device, stats);
+        uint64_t n = 0; rt_output_floats(&prm, &n);
+        HIP_TRY(ctx, ctx->shard_tmp.ensure(n * 4));
+        const int r = render_checked(ctx, scene, cam, &prm, ctx->shard_tmp.p, stats);
+        if (r != RT_OK) return r;
+        HIP_TRY(ctx, rtk::launch_write_color((const float*)ctx->shard_tmp.p, prm.width * prm.height, prm.samples_per_pixel, (uint8_t*)frame_device, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (stats) { stats->n_devices = 1; stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+        return RT_OK;
+    }
+    if (rank == 0 && kind == RT_OUT_RGB_SUM_F32) mine = gather;  // slot 0
+    {
+        const int r = render_checked(ctx, scene, cam, &prm, kind == RT_OUT_RGB_SUM_F32 ? mine : (void*)shard_f32, stats);
+        if (r != RT_OK) return r;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0)); HIP_TRY(ctx, hipEventCreate(&e1));
+    struct Ev { hipEvent_t a, b; ~Ev() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } ev{e0, e1};
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    if (kind == RT_OUT_RGB8) {
+        // write_color on the shard (an elementwise map over its compact tile buffer; clipped pixels are 0 and stay 0)
+        uint8_t* dst = rank == 0 ? (uint8_t*)gather : shard_u8;
+        HIP_TRY(ctx, rtk::launch_write_color(shard_f32, (uint32_t)g.per_shard_px, prm.samples_per_pixel, dst, ctx->stream));
+        mine = dst;
+    }
+    // ---- the one exchange of the path: every peer sends its shard straight to the root (its own xGMI link) ----
+    const ncclDataType_t dt = kind == RT_OUT_RGB8 ? ncclUint8 : ncclFloat32;
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    if (rank == 0) {
+        NCCL_TRY(ctx, R->GroupStart());
+        for (int r = 1; r < world; ++r) {
+            const ncclResult_t q = R->Recv((char*)gather + (size_t)r * shard_elems * elem, shard_elems, dt, r, comm, ctx->stream);
+            if (q != ncclSuccess) { (void)R->GroupEnd(); return set_err(ctx, RT_ERR_DEVICE, std::string("ncclRecv: ") + R->GetErrorString(q)); }
+        }
+        NCCL_TRY(ctx, R->GroupEnd());
+        if (kind == RT_OUT_RGB8) HIP_TRY(ctx, rtk::launch_untile_u8((const uint8_t*)gather, (uint8_t*)frame_device, prm.width, prm.height, g.tl.ts, g.tl.tiles_x,
+                                                                    (uint32_t)world, (uint64_t)shard_elems, ctx->stream));
+        else HIP_TRY(ctx, rtk::launch_untile_f32((const float*)gather, (float*)frame_device, prm.width, prm.height, g.tl.ts, g.tl.tiles_x, (uint32_t)world,
+                                                 (uint64_t)shard_elems, ctx->stream));
+    } else {
+        NCCL_TRY(ctx, R->Send(mine, shard_elems, dt, 0, comm, ctx->stream));
+    }
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        float ms = 0.f; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) stats->gather_ms = ms;
+        stats->n_devices = (uint32_t)world;
+        stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+void rti::comm_release(RtCtx* ctx) {
+    if (ctx && ctx->comm) { const Rccl* R = rccl(); if (R) (void)R->CommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; ctx->comm_world = 1; ctx->comm_rank = 0; }
+}
+
+struct RtMultiCtx {
+    std::vector<RtCtx*> ctx;
+    std::string err;
+    void* host_pinned = nullptr; size_t host_pinned_bytes = 0;
+    DevBuf frame;   // full frame on the root device before it goes to the host
+};
+struct RtMultiScene { std::vector<RtScene*> scene; };
+
+extern "C" {
+
+int rt_comm_unique_id(uint8_t* id_out) {
+    if (!id_out) return set_err(nullptr, RT_ERR_INVALID, "id_out is null");
+    const Rccl* R = rccl();
+    if (!R) return set_err(nullptr, RT_ERR_DEVICE, g_rccl.error);
+    ncclUniqueId id;
+    NCCL_TRY(nullptr, R->GetUniqueId(&id));
+    std::memcpy(id_out, id.internal, RT_COMM_ID_BYTES);
+    return RT_OK;
+}
+
+int rt_comm_init_rank(RtCtx* ctx, const uint8_t* id_in, int rank, int world) {
+    if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
+    if (!id_in || world < 1 || rank < 0 || rank >= world) return set_err(ctx, RT_ERR_INVALID, "bad id / rank / world");
+    const Rccl* R = rccl();
+    if (!R) return set_err(ctx, RT_ERR_DEVICE, g_rccl.error);
+    comm_release(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id; std::memcpy(id.internal, id_in, RT_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(ctx, R->CommInitRank(&comm, world, id, rank));
+    ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
+    return RT_OK;
+}
+
+int rt_comm_selftest(RtCtx* ctx) {
+    if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
+    if (!ctx->comm) return set_err(ctx, RT_ERR_INVALID, "no communicator on this context (rt_comm_init_rank)");
+    const Rccl* R = rccl();
+    if (!R) return set_err(ctx, RT_ERR_DEVICE, g_rccl.error);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    constexpr size_t n = 1 << 16;
+    std::vector<uint8_t> src(n), dst(n, 0);
+    for (size_t i = 0; i < n; ++i) src[i] = (uint8_t)((i * 2654435761u) >> 13);
+    DevBuf a, b;
+    HIP_TRY(ctx, a.ensure(n)); HIP_TRY(ctx, b.ensure(n));
+    struct Free { DevBuf &x, &y; ~Free() { x.release(); y.release(); } } fr{a, b};
+    HIP_TRY(ctx, hipMemcpyAsync(a.p, src.data(), n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(b.p, 0, n, ctx->stream));
+    NCCL_TRY(ctx, R->GroupStart());
+    const ncclResult_t s = R->Send(a.p, n, ncclUint8, ctx->comm_rank, (ncclComm_t)ctx->comm, ctx->stream);
+    const ncclResult_t r = R->Recv(b.p, n, ncclUint8, ctx->comm_rank, (ncclComm_t)ctx->comm, ctx->stream);
+    NCCL_TRY(ctx, R->GroupEnd());
+    if (s != ncclSuccess || r != ncclSuccess) return set_err(ctx, RT_ERR_DEVICE, "self send/recv was refused");
+    HIP_TRY(ctx, hipMemcpyAsync(dst.data(), b.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (std::memcmp(src.data(), dst.data(), n) != 0) return set_err(ctx, RT_ERR_DEVICE, "self send/recv returned other bytes");
+    return RT_OK;
+}
+
+int rt_render_gather(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* params, uint32_t output_kind, void* frame_device, RtStats* stats) {
+    if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
+    if (!scene || !cam || !params) return set_err(ctx, RT_ERR_INVALID, "scene / cam / params is null");
+    return render_gather_rank(ctx, scene, cam, params, output_kind, frame_device, stats);
+}
+
+int rt_untile_device(RtCtx* ctx, const RtParams* params, uint32_t kind, const void* gathered_device, void* frame_device) {
+    if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
+    if (!params || !gathered_device || !frame_device || kind > RT_OUT_RGB8) return set_err(ctx, RT_ERR_INVALID, "bad argument");
+    const uint32_t world = params->shard_count <= 1u ? 1u : params->shard_count;
+    ShardGeom g; if (shard_geom(*params, world, g) != RT_OK) return set_err(ctx, RT_ERR_INVALID, "bad tiling parameters");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t shard_elems = g.per_shard_px * 3;
+    if (kind == RT_OUT_RGB8) HIP_TRY(ctx, rtk::launch_untile_u8((const uint8_t*)gathered_device, (uint8_t*)frame_device, params->width, params->height, g.tl.ts, g.tl.tiles_x,
+                                                                world, shard_elems, ctx->stream));
+    else HIP_TRY(ctx, rtk::launch_untile_f32((const float*)gathered_device, (float*)frame_device, params->width, params->height, g.tl.ts, g.tl.tiles_x, world, shard_elems,
+                                             ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+const char* rt_last_error_multi(const RtMultiCtx* m) { return m ? m->err.c_str() : g_last_error.c_str(); }
+
+int rt_ctx_destroy_multi(RtMultiCtx* m) {
+    if (!m) return RT_OK;
+    if (!m->ctx.empty() && m->ctx[0]) { (void)hipSetDevice(m->ctx[0]->device); m->frame.release(); if (m->host_pinned) (void)hipHostFree(m->host_pinned); }
+    for (RtCtx* c : m->ctx) rt_ctx_destroy(c);
+    delete m;
+    return RT_OK;
+}
+
+int rt_ctx_create_multi(const int* device_ids, int n, RtMultiCtx** out) {
+    if (!out) return set_err(nullptr, RT_ERR_INVALID, "out_ctx is null");
+    *out = nullptr;
+    if (!device_ids || n < 1 || n > 64) return set_err(nullptr, RT_ERR_INVALID, "device_ids / n_devices");
+    for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (device_ids[i] == device_ids[j]) return set_err(nullptr, RT_ERR_INVALID, "a device is listed twice");
+    RtMultiCtx* m = new RtMultiCtx();
+    for (int i = 0; i < n; ++i) {
+        RtCtx* c = nullptr;
+        const int r = rt_ctx_create(device_ids[i], nullptr, &c);
+        if (r != RT_OK) { rt_ctx_destroy_multi(m); return r; }
+        m->ctx.push_back(c);
+    }
+    const Rccl* R = rccl();
+    if (!R) { rt_ctx_destroy_multi(m); return set_err(nullptr, RT_ERR_DEVICE, g_rccl.error); }
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    const ncclResult_t q = R->CommInitAll(comms.data(), n, device_ids);   // single process: one communicator per device
+    if (q != ncclSuccess) { rt_ctx_destroy_multi(m); return set_err(nullptr, RT_ERR_DEVICE, std::string("ncclCommInitAll: ") + R->GetErrorString(q)); }
+    for (int i = 0; i < n; ++i) { m->ctx[i]->comm = comms[i]; m->ctx[i]->comm_rank = i; m->ctx[i]->comm_world = n; }
+    *out = m;
+    return RT_OK;
+}
+
+int rt_scene_destroy_multi(RtMultiCtx* m, RtMultiScene* s) {
+    if (!s) return RT_OK;
+    for (size_t i = 0; i < s->scene.size(); ++i) rt_scene_destroy(m && i < m->ctx.size() ? m->ctx[i] : nullptr, s->scene[i]);
+    delete s;
+    return RT_OK;
+}
+
+int rt_scene_upload_multi(RtMultiCtx* m, const RtSceneDesc* desc, RtMultiScene** out) {
+    if (!m || !desc || !out) return set_err(nullptr, RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    RtMultiScene* s = new RtMultiScene();
+    for (RtCtx* c : m->ctx) {
+        RtScene* sc = nullptr;
+        const int r = rt_scene_upload(c, desc, &sc);
+        if (r != RT_OK) { m->err = c->err; rt_scene_destroy_multi(m, s); return r; }
+        s->scene.push_back(sc);
+    }
+    *out = s;
+    return RT_OK;
+}
+
+static int render_multi(RtMultiCtx* m, const RtMultiScene* s, const RtCamera* cam, const RtParams* prm, uint32_t kind, void* host_out, RtStats* stats) {
+    if (!m) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
+    if (!s || !cam || !prm || !host_out || s->scene.size() != m->ctx.size()) { m->err = "scene / cam / params / output"; return set_err(nullptr, RT_ERR_INVALID, m->err); }
+    const int n = (int)m->ctx.size();
+    const auto t0 = std::chrono::steady_clock::now();
+    RtCtx* root = m->ctx[0];
+    if (hipSetDevice(root->device) != hipSuccess) { m->err = "hipSetDevice"; return RT_ERR_DEVICE; }
+    const size_t elem = kind == RT_OUT_RGB8 ? 1 : 4, frame_bytes = (size_t)prm->width * prm->height * 3 * elem;
+    if (m->frame.ensure(frame_bytes) != hipSuccess) { m->err = "out of device memory for the frame"; return set_err(nullptr, RT_ERR_OOM, m->err); }
+    if (m->host_pinned_bytes < frame_bytes) {
+        if (m->host_pinned) (void)hipHostFree(m->host_pinned);
+        m->host_pinned = nullptr; m->host_pinned_bytes = 0;
+        if (hipHostMalloc(&m->host_pinned, frame_bytes, hipHostMallocDefault) == hipSuccess) m->host_pinned_bytes = frame_bytes;
+    }
+    // one host thread per device: each runs its own wavefront loop (it has host round trips) and its side of the exchange
+    std::vector<int> rc((size_t)n, RT_OK);
+    std::vector<RtStats> st((size_t)n);
+    std::vector<std::thread> th;
+    for (int i = 1; i < n; ++i) th.emplace_back([&, i] { rc[i] = render_gather_rank(m->ctx[i], s->scene[i], cam, prm, kind, nullptr, &st[i]); });
+    rc[0] = render_gather_rank(root, s->scene[0], cam, prm, kind, m->frame.p, &st[0]);
+    for (auto& t : th) t.join();
+    for (int i = 0; i < n; ++i) if (rc[i] != RT_OK) { m->err = "device " + std::to_string(m->ctx[i]->device) + ": " + m->ctx[i]->err; return set_err(nullptr, rc[i], m->err); }
+    // frame -> host (through pinned memory when it could be had)
+    (void)hipSetDevice(root->device);
+    hipError_t e = hipSuccess;
+    if (m->host_pinned) {
+        e = hipMemcpyAsync(m->host_pinned, m->frame.p, frame_bytes, hipMemcpyDeviceToHost, root->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(root->stream);
+        if (e == hipSuccess) std::memcpy(host_out, m->host_pinned, frame_bytes);
+    } else {
+        e = hipMemcpyAsync(host_out, m->frame.p, frame_bytes, hipMemcpyDeviceToHost, root->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(root->stream);
+    }
+    if (e != hipSuccess) { m->err = std::string("frame copy: ") + hipGetErrorString(e); return set_err(nullptr, RT_ERR_DEVICE, m->err); }
+    if (stats) {
+        *stats = st[0];
+        for (int i = 1; i < n; ++i) {
+            stats->samples += st[i].samples; stats->segments += st[i].segments; stats->node_tests += st[i].node_tests;
+            for (int k = 0; k < RT_N_PRIM_TYPES; ++k) stats->prim_tests[k] += st[i].prim_tests[k];
+            stats->extend_ms = std::max(stats->extend_ms, st[i].extend_ms); stats->shade_ms = std::max(stats->shade_ms, st[i].shade_ms);
+            stats->other_ms = std::max(stats->other_ms, st[i].other_ms);
+        }
+        stats->n_devices = (uint32_t)n;
+        stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RT_OK;
+}
+
+int rt_render_multi(RtMultiCtx* m, const RtMultiScene* s, const RtCamera* cam, const RtParams* prm, float* rgb_sum_host, RtStats* stats) {
+    return render_multi(m, s, cam, prm, RT_OUT_RGB_SUM_F32, rgb_sum_host, stats);
+}
+int rt_render_multi_rgb8(RtMultiCtx* m, const RtMultiScene* s, const RtCamera* cam, const RtParams* prm, uint8_t* rgb8_host, RtStats* stats) {
+    return render_multi(m, s, cam, prm, RT_OUT_RGB8, rgb8_host, stats);
+}
+
+}  // extern "C"

@@ -1,11 +1,18 @@
-"""Framebuffer sharding across the GPUs of one node: one process per GPU, tiles dealt round-robin
-(tile t belongs to rank t % world), one RCCL gather of equal-sized shard buffers to rank 0.
+"""Framebuffer sharding across the GPUs of one node, one process per GPU (torchrun-style launchers).
 
-The path has no other exchange step: pixels are independent (main.rs:731-784 carries no cross-pixel
-state), the scene is replicated. torch / torch.distributed are plumbing here (device memory and the
-collective); the render itself is the C ABI's rt_render_device."""
+The data path is the C ABI's: every rank renders its tiles (tile t belongs to rank t % world) and `rt_render_gather`
+(csrc/rt_multi.cpp) moves the shards to rank 0 with ONE grouped ncclSend/ncclRecv exchange — RCCL called from the library,
+no torch in it — and puts the tiles in place on rank 0's device. The launcher's own channel (torch.distributed, any backend:
+gloo will do) only carries the 128-byte RCCL id from rank 0 to the other ranks: `init_comm`.
+
+The path has no other exchange step: pixels are independent (main.rs:731-784 carries no cross-pixel state), the scene is
+replicated. A single-process host drives all GPUs through `api.MultiContext` (rt_render_multi) instead.
+
+`render_sharded` is the older route for callers that already hold a torch process group and want the shards as torch tensors:
+the same shard layout, gathered with torch.distributed; `assemble` = rt_untile on the host."""
 import numpy as np
 
+from . import _abi as A
 from . import api
 
 
@@ -20,8 +27,34 @@ def shard_floats(base, world, tile_size=32):
     return api.output_floats(shard_params(base, 0, world, tile_size))
 
 
+def init_comm(ctx, rank, world, dist=None):
+    """Attach an RCCL communicator to `ctx` (rt_comm_init_rank, collective). `dist` = an initialised torch.distributed
+    module (or anything with broadcast_object_list) used ONLY to hand rank 0's id to the other ranks."""
+    ids = [api.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        if dist is None:
+            raise ValueError("world > 1 needs a channel for the RCCL id")
+        dist.broadcast_object_list(ids, src=0)
+    ctx.comm_init_rank(ids[0], rank, world)
+    return ids[0]
+
+
+def render_gathered(ctx, scene, cam, base, rank, output_kind=A.RT_OUT_RGB_SUM_F32, device=None, tile_size=32):
+    """rt_render_gather on this rank. Rank 0 returns (frame tensor (H, W, 3) on `device`: float32 sums or uint8, stats);
+    the other ranks return (None, stats)."""
+    import torch
+    prm = shard_params(base, 0, 1, tile_size)     # shard fields are ignored by rt_render_gather (the communicator's rank/world count)
+    frame = None
+    if rank == 0:
+        frame = torch.empty((base.height, base.width, 3), dtype=torch.uint8 if output_kind == A.RT_OUT_RGB8 else torch.float32, device=device)
+        if frame.is_cuda:
+            torch.cuda.current_stream(frame.device).synchronize()   # the allocation is ordered before the library's stream touches it
+    st = ctx.render_gather(scene, cam, prm, output_kind, frame.data_ptr() if frame is not None else None)
+    return frame, st
+
+
 def render_sharded(render_shard, base, rank, world, dist=None, tile_size=32, device=None):
-    """Render this rank's tiles and gather all shards on rank 0.
+    """Render this rank's tiles and gather all shards on rank 0 with torch.distributed.
 
     render_shard(params, out_tensor) fills out_tensor (1-D float32 torch tensor on `device`, zero
     padded) with this rank's tiles; on the GPU path it calls Context.render_device with
@@ -30,6 +63,8 @@ def render_sharded(render_shard, base, rank, world, dist=None, tile_size=32, dev
     prm = shard_params(base, rank, world, tile_size)
     n = shard_floats(base, world, tile_size)
     out = torch.zeros(n, dtype=torch.float32, device=device)
+    if out.is_cuda:
+        torch.cuda.current_stream(out.device).synchronize()   # torch's fill is done before the library's own stream writes the buffer
     render_shard(prm, out)
     if world == 1 or dist is None:
         return out.unsqueeze(0)

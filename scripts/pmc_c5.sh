@@ -4,6 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 TAG=${1:-C5}; SPP=${2:-16}
+python3 -c "import sys; sys.path.insert(0,'.'); import importlib.util as u; sp=u.spec_from_file_location('b','ray-tracer-archive_amd/build.py'); b=u.module_from_spec(sp); sp.loader.exec_module(b); print(b.source_hash())" > gpurun_out/pmc${TAG}_source_hash.txt
 for i in 1 2 3 4; do
   case $i in
     1) C="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAIT_ANY";;

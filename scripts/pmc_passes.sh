@@ -2,6 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 TAG=${1:-A}; SCENE=${2:-book1}; W=${3:-1200}; H=${4:-800}; SPP=${5:-500}
+python3 -c "import sys; sys.path.insert(0,'.'); import importlib.util as u; sp=u.spec_from_file_location('b','ray-tracer-archive_amd/build.py'); b=u.module_from_spec(sp); sp.loader.exec_module(b); print(b.source_hash())" > gpurun_out/pmc${TAG}_source_hash.txt
 for i in 1 2 3 4 5; do
   case $i in
     1) C="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY";;

@@ -70,3 +70,57 @@ def test_sharded_gather_gloo(world, W, H, ts):
         p.join(120)
         assert p.exitcode == 0
     assert q.get() is True
+
+
+def id_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import rta
+        pkg = rta.load()
+        from importlib import import_module
+        D = import_module("ray_tracer_archive_amd.distributed")
+        api = import_module("ray_tracer_archive_amd.api")
+        api.comm_unique_id = lambda: bytes(range(128))        # rank 0's id (the real one needs librccl + a GPU)
+
+        class FakeCtx:
+            def comm_init_rank(self, uid, r, w):
+                self.got = (bytes(uid), r, w)
+        c = FakeCtx()
+        D.init_comm(c, rank, world, dist)
+        q.put(c.got == (bytes(range(128)), rank, world))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_id_travels_over_the_launchers_channel():
+    """distributed.init_comm: rank 0's 128-byte id reaches every rank over torch.distributed (gloo here) and each rank attaches with
+    its own rank / world. The communicator itself is exercised on the GPU box (tests/test_gpu_multi.py)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = free_port()
+    procs = [ctx.Process(target=id_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get() is True and q.get() is True
+
+
+def test_untile_rgb8_matches_untile():
+    sys.path.insert(0, ROOT)
+    import rta
+    pkg = rta.load()
+    from importlib import import_module
+    D = import_module("ray_tracer_archive_amd.distributed")
+    for (W, H, ts, world) in [(70, 45, 8, 3), (100, 60, 16, 2), (33, 17, 32, 8)]:
+        base = pkg.make_params(W, H, 4)
+        n = D.shard_floats(base, world, ts)
+        g = np.random.default_rng(W).integers(0, 255, size=(world, n)).astype(np.uint8)
+        a = pkg.untile_rgb8(D.shard_params(base, 0, world, ts), g.reshape(-1))
+        b = D.assemble(base, g.astype(np.float32), world, ts)
+        assert np.array_equal(a.astype(np.float32), b)

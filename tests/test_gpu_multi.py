@@ -1,0 +1,97 @@
+"""Multi-GPU entry points of the C ABI (include/rt_hip.h, csrc/rt_multi.cpp) on the ONE GPU of the test box (-m gpu).
+
+The 8-GPU run belongs to the driver; what can be pinned here is every piece of it: the single-process multi-device context
+with one device (ncclCommInitAll of one), the RCCL plumbing itself (communicator from a unique id + a grouped ncclSend/ncclRecv
+round trip on the context's stream), write_color applied to a shard's compact tile buffer before the gather, and the root's
+untile kernel against the host's rt_untile, for f32 and RGB8. That every shard of an image equals the unsharded frame bit for
+bit is tests/test_gpu_parity.py::test_bit_exact_invariances and the 8-shard case of tests/test_gpu_full_frames.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def book1(pkg, gpu):
+    hs = pkg.HostScene("book1", 1)
+    return hs, gpu.upload(hs.desc)
+
+
+def test_multi_context_of_one_device(pkg, gpu, book1):
+    hs, scene = book1
+    W, H, SPP = 150, 90, 6
+    cam = hs.camera(W / H)
+    prm = pkg.make_params(W, H, SPP, seed=4)
+    ref, _ = gpu.render(scene, cam, prm)
+    m = pkg.MultiContext([0])
+    ms = m.upload(hs.desc)
+    img, st = m.render(ms, cam, prm)
+    assert np.array_equal(img, ref) and st["n_devices"] == 1 and st["samples"] == W * H * SPP
+    rgb8, st8 = m.render_rgb8(ms, cam, prm)
+    assert np.array_equal(rgb8, pkg.tonemap(ref, SPP))
+    with pytest.raises(pkg.RtError):
+        pkg.MultiContext([0, 0])                     # a device listed twice
+    with pytest.raises(pkg.RtError):
+        pkg.MultiContext([])
+    ms.close(); m.close()
+
+
+def test_rccl_communicator_and_exchange(pkg, book1):
+    """librccl loads, a communicator attaches to the context, and a grouped send/recv completes on its stream (world 1)."""
+    A = pkg._abi
+    hs, _ = book1
+    ctx = pkg.Context(0)
+    with pytest.raises(pkg.RtError):
+        ctx.comm_selftest()                          # no communicator yet
+    uid = pkg.comm_unique_id()
+    assert len(uid) == A.RT_COMM_ID_BYTES and any(uid)
+    ctx.comm_init_rank(uid, 0, 1)
+    ctx.comm_selftest()
+    # rt_render_gather with a world of one: the frame in caller-owned device memory, f32 and RGB8
+    import torch
+    from importlib import import_module
+    D = import_module("ray_tracer_archive_amd.distributed")
+    scene = ctx.upload(hs.desc)
+    W, H, SPP = 130, 70, 5
+    cam = hs.camera(W / H)
+    base = pkg.make_params(W, H, SPP, seed=8)
+    ref, _ = ctx.render(scene, cam, base)
+    frame, st = D.render_gathered(ctx, scene, cam, base, 0, A.RT_OUT_RGB_SUM_F32, device="cuda")
+    assert np.array_equal(frame.cpu().numpy(), ref) and st["n_devices"] == 1
+    frame8, _ = D.render_gathered(ctx, scene, cam, base, 0, A.RT_OUT_RGB8, device="cuda")
+    assert np.array_equal(frame8.cpu().numpy(), pkg.tonemap(ref, SPP))
+    ctx.close()
+
+
+@pytest.mark.parametrize("world,tile", [(2, 32), (3, 16), (8, 32)])
+def test_shard_resolve_and_device_untile(pkg, gpu, book1, world, tile):
+    """What rt_render_gather does around the exchange, step by step with the shards of one GPU: write_color on each shard's
+    compact buffer, then the root's untile kernel — equal to the unsharded frame (f32) and to its tone-mapped bytes (RGB8)."""
+    import torch
+    from importlib import import_module
+    D = import_module("ray_tracer_archive_amd.distributed")
+    A = pkg._abi
+    hs, scene = book1
+    W, H, SPP = 150, 90, 4                        # not multiples of the tile size: clipped edge tiles
+    cam = hs.camera(W / H)
+    base = pkg.make_params(W, H, SPP, seed=5)
+    ref, _ = gpu.render(scene, cam, base)
+    n = D.shard_floats(base, world, tile)
+    g32 = torch.zeros((world, n), dtype=torch.float32, device="cuda")
+    g8 = torch.zeros((world, n), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for r in range(world):
+        prm = D.shard_params(base, r, world, tile)
+        gpu.render_device(scene, cam, prm, g32[r].data_ptr())
+        gpu.resolve_device(g32[r].data_ptr(), n // 3, 1, SPP, g8[r].data_ptr())          # a shard buffer is just n/3 pixels
+    prm0 = D.shard_params(base, 0, world, tile)
+    f32 = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    f8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu.untile_device(prm0, A.RT_OUT_RGB_SUM_F32, g32.data_ptr(), f32.data_ptr())
+    gpu.untile_device(prm0, A.RT_OUT_RGB8, g8.data_ptr(), f8.data_ptr())
+    assert np.array_equal(f32.cpu().numpy(), ref)
+    assert np.array_equal(f8.cpu().numpy(), pkg.tonemap(ref, SPP))
+    # and the host helpers agree with the device kernel
+    assert np.array_equal(D.assemble(base, g32.cpu().numpy(), world, tile), ref)
+    assert np.array_equal(pkg.untile_rgb8(prm0, g8.cpu().numpy().reshape(-1)), pkg.tonemap(ref, SPP))
