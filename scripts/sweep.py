@@ -62,9 +62,9 @@ else:
         for pool in pools:
             env = dict(os.environ, RT_HIP_LIB=os.path.join(ROOT, "ray-tracer-archive_amd", "lib", "variants", f"librt_hip_{n}.so"))
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--spp", os.environ.get("SPP", "200"),
-                                "--pool-slots", str(pool)], env=env, capture_output=True, text=True)
+                                "--pool-slots", str(pool), "--no-variants"], env=env, capture_output=True, text=True)
             try:
                 j = json.loads(r.stdout.strip().splitlines()[-1])
-                print(f"{n:8s} pool {pool:9d}: {j['value']:8.1f} Msamples/s  extend {j['roofline']['extend_ms_per_step']:7.1f} ms shade {j['roofline']['shade_ms_per_step']:6.1f} ms  step {j['ms_per_step']:7.1f} ms", flush=True)
+                print(f"{n:8s} pool {pool:9d}: {j['value']:8.1f} Msamples/s  extend {j['kernel_ms_per_step']['k_extend']:7.1f} ms shade {j['kernel_ms_per_step']['k_shade']:6.1f} ms other {j['kernel_ms_per_step']['generate+resolve']:5.1f} ms  step {j['ms_per_step']:7.1f} ms", flush=True)
             except Exception as e:
                 print(n, pool, "FAILED", r.stdout[-300:], r.stderr[-600:], flush=True)
