@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -40,8 +41,12 @@ std::once_flag g_rccl_once;
 
 const Rccl* rccl() {
     std::call_once(g_rccl_once, [] {
+        // a copy the process already holds (PyTorch links its own librccl.so.1) is shared, never doubled; RT_RCCL_LIB overrides
+        const char* env = getenv("RT_RCCL_LIB");
+        if (env && env[0]) g_rccl.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        if (!g_rccl.handle) g_rccl.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) { g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.handle) break; }
+        for (const char* n : names) { if (g_rccl.handle) break; g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
         if (!g_rccl.handle) { g_rccl.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
         auto sym = [&](const char* n) { void* p = dlsym(g_rccl.handle, n); if (!p && g_rccl.error.empty()) g_rccl.error = std::string("librccl lacks ") + n; return p; };
         g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");

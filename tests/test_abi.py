@@ -76,3 +76,27 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read().lower()
                 assert "oracle" not in txt and "liboracle" not in txt, os.path.join(dp, f)
+
+
+def test_rust_shim_covers_the_header():
+    """docs/gpu_ffi.rs (the `extern "C"` block a maintainer adds as raytracer/src/gpu_ffi.rs; never compiled here: no Rust toolchain) binds
+    every function include/rt_hip.h declares, and its #[repr(C)] structs list the header's fields in the header's order."""
+    rs = open(os.path.join(ROOT, "docs", "gpu_ffi.rs")).read()
+    bound = sorted(set(re.findall(r"pub fn (rt_[a-z0-9_]+)\s*\(", rs)))
+    assert bound == declared_functions("rt_hip.h")
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rt_hip.h")).read(), flags=re.S)
+    for name in ["RtVec3", "RtCamera", "RtTexture", "RtPerlin", "RtImage", "RtMaterial", "RtHittable", "RtSceneDesc", "RtParams", "RtStats", "RtCompileInfo"]:
+        body_c = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr, flags=re.S).group(1)
+        fields_c = []
+        for decl in body_c.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):                        # "RtVec3 u, v, w" and "uint32_t width, height"
+                m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])*\s*$", part.strip())
+                fields_c.append(m.group(1))
+        body_rs = re.search(r"pub struct %s \{(.*?)\n?\}" % name, rs, flags=re.S).group(1)
+        fields_rs = re.findall(r"pub ([A-Za-z_][A-Za-z0-9_]*)\s*:", body_rs)
+        assert fields_rs == fields_c, (name, fields_rs, fields_c)
+    patch = open(os.path.join(ROOT, "docs", "main_rs.patch")).read()
+    assert "730,784c" in patch and "rt_render_multi_rgb8" in patch and "24a" in patch

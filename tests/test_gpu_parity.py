@@ -14,8 +14,12 @@ pytestmark = pytest.mark.gpu
 
 
 def compare(img, ref, spp):
+    import inspect
+    from conftest import record_metric
     d = np.abs(img.astype(np.float64) - ref) / spp
-    return d.mean(), float((d.max(axis=2) > 2e-3).mean())
+    m, bad = d.mean(), float((d.max(axis=2) > 2e-3).mean())
+    record_metric(config="parity", crop=inspect.stack()[1].function, mean=float(m), bad=bad, spp=spp)
+    return m, bad
 
 
 @pytest.fixture(scope="module")

@@ -13,6 +13,9 @@ def check(pkg, orc, gpu, desc, cam, W, H, SPP, mean_tol=5e-4, bad_tol=0.03, seg_
     ref, ost = orc.render(desc, cam, prm, precision=64, n_threads=8, count=True)
     d = np.abs(img.astype(np.float64) - ref) / SPP
     bad = float((d.max(axis=2) > 2e-3).mean())
+    import inspect
+    from conftest import record_metric
+    record_metric(config="scenes", crop=inspect.stack()[1].function, mean=float(d.mean()), bad=bad, seg=abs(st["segments"] - ost["segments"]) / ost["segments"], spp=SPP)
     assert np.isfinite(img).all()
     assert d.mean() <= mean_tol and bad <= bad_tol, (d.mean(), bad)
     assert abs(st["segments"] - ost["segments"]) <= max(8, seg_tol * ost["segments"]), (st["segments"], ost["segments"])
