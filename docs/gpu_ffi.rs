@@ -170,6 +170,7 @@ extern "C" {
 
     // ---- scene-compiler introspection (host only) ----
     pub fn rt_scene_compile_info(desc: *const RtSceneDesc, out: *mut RtCompileInfo) -> c_int;
+    pub fn rt_scene_top_layout_check(desc: *const RtSceneDesc, max_top: u32, out_n_top: *mut u64) -> c_int;
     pub fn rt_scene_compile_dump(desc: *const RtSceneDesc, nodes: *mut c_void, cap_nodes: u64, spheres: *mut f32,
                                  sphere_meta: *mut u32, cap_spheres: u64) -> c_int;
 }

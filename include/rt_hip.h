@@ -319,6 +319,12 @@ int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out);
 int rt_scene_compile_dump(const RtSceneDesc* desc, void* nodes, uint64_t cap_nodes,
                           float* spheres, uint32_t* sphere_meta, uint64_t cap_spheres);
 
+/* Builds the layout used when a scene does not fit LDS as a whole — the array in HBM plus an LDS copy of the top of the tree (at most
+   max_top records), linked in one address space — and checks it on the host: the walk that passes every box enumerates all records
+   in pre-order, every skip link lands where the plain array's does, both copies of a top record agree. *out_n_top = records in
+   the top (0: no top was built, e.g. the whole scene fits). */
+int rt_scene_top_layout_check(const RtSceneDesc* desc, uint32_t max_top, uint64_t* out_n_top);
+
 const char* rt_last_error(const RtCtx* ctx);  /* ctx may be NULL: last error of this thread */
 uint32_t rt_abi_version(void);
 

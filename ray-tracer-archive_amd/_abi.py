@@ -96,7 +96,7 @@ RT_HIP_SYMBOLS = ["rt_ctx_create", "rt_ctx_destroy", "rt_scene_upload", "rt_scen
                   "rt_render_device", "rt_untile", "rt_resolve_device", "rt_last_error", "rt_abi_version", "rt_scene_compile_info",
                   "rt_scene_compile_dump", "rt_ctx_create_multi", "rt_ctx_destroy_multi", "rt_scene_upload_multi", "rt_scene_destroy_multi",
                   "rt_render_multi", "rt_render_multi_rgb8", "rt_last_error_multi", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_selftest",
-                  "rt_render_gather", "rt_untile_rgb8", "rt_untile_device"]
+                  "rt_render_gather", "rt_untile_rgb8", "rt_untile_device", "rt_scene_top_layout_check"]
 RT_HOST_SYMBOLS = ["rt_host_scene_create", "rt_host_scene_desc", "rt_host_scene_camera", "rt_host_scene_destroy", "rt_host_camera_new",
                    "rt_host_write_color", "rt_host_tonemap", "rt_host_write_png"]
 
@@ -157,6 +157,8 @@ def declare(lib):
     lib.rt_render_gather.argtypes = [vp, vp, P(RtCamera), P(RtParams), u32, vp, P(RtStats)]
     lib.rt_untile_device.restype = i32
     lib.rt_untile_device.argtypes = [vp, P(RtParams), u32, vp, vp]
+    lib.rt_scene_top_layout_check.restype = i32
+    lib.rt_scene_top_layout_check.argtypes = [P(RtSceneDesc), u32, P(u64)]
     lib.rt_host_scene_create.restype = i32
     lib.rt_host_scene_create.argtypes = [C.c_char_p, u64, u64, u64, P(C.c_uint8), u32, u32, P(vp)]
     lib.rt_host_scene_desc.restype = P(RtSceneDesc)

@@ -55,6 +55,12 @@ constexpr uint32_t NODE_STRIDE_HBM = 32, NODE_STRIDE_LDS = RT_NODE_STRIDE_LDS;
 // lane states of k_extend kept in the `pend` word (leaf type 0 = no primitive work):
 constexpr uint32_t LEAF_IDLE = 1u << 24;   // the lane holds no ray
 constexpr uint32_t LEAF_DONE = 2u << 24;   // the lane's ray has visited every node
+// Layout with the top of the tree in LDS (kernels.hip M_TOP; rt_api.cpp device_nodes_top): `skip_bytes` and, for an inner record
+// (leaf type 0), the leaf word are addresses in ONE space: [0, top_bytes) = the record's slot in the LDS copy of the top,
+// top_bytes + 32 * i = record i of the HBM array. A record with a leaf payload continues at `skip_bytes` (its subtree is itself).
+// Hit links live in the 28 low bits of the leaf word, so the space is 256 MB (8 M records); larger scenes stay in HBM alone.
+constexpr uint32_t LEAF_DONE_TOP = 15u << 28;   // leaf word of the closing record in that layout
+constexpr uint32_t TOP_SPACE_BYTES = 1u << 28;
 
 // ---- primitives: one geometry array per type (16-byte records) + one u32 `meta` per primitive ----
 // meta = material id (22 bits) | wrap id << 22 (10 bits)

@@ -365,12 +365,20 @@ constexpr int kLeafBatch = RT_LEAF_BATCH;
 // in separate passes so that each pass keeps many lanes busy: a primitive test (f64 refinement) costs
 // several node visits, and in lock step with node visits it would run with one or two active lanes.
 // Per lane the ORDER of events is unchanged: the leaf is tested before the lane visits its next node.
-template <bool LDS, uint32_t FEAT, bool COUNT, uint32_t TPB>
+// MODE: where the node records live. M_HBM: the array in HBM (L2 / Infinity Cache). M_LDS: the whole scene (nodes + spheres) staged in
+// LDS. M_TOP: the scene does not fit, so the TOP of the tree (every node above a depth cut, rt_api.cpp: device_nodes_top) is staged
+// in LDS and the rest stays in HBM; one address space covers both (offsets below top_bytes are LDS slots, the others HBM offsets
+// + top_bytes), every record carries its own links in that space (`skip`, and for an inner node the hit link in the leaf word),
+// so a walk moves between the two memories without knowing it.
+enum : int { M_HBM = 0, M_LDS = 1, M_TOP = 2 };
+template <int MODE, uint32_t FEAT, bool COUNT, uint32_t TPB>
 __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
                                                  uint32_t* __restrict__ head, uint32_t* __restrict__ count_out_to_zero,
                                                  unsigned long long* __restrict__ counters, RenderDev rd) {
     extern __shared__ float4 lds[];
+    constexpr bool LDS = MODE == M_LDS, TOP = MODE == M_TOP;
     constexpr uint32_t kStride = LDS ? rtd::NODE_STRIDE_LDS : rtd::NODE_STRIDE_HBM;   // bytes per node record (device_types.h)
+    constexpr uint32_t kDone = TOP ? rtd::LEAF_DONE_TOP : rtd::LEAF_DONE;              // leaf word of the closing record
     if (blockIdx.x == 0 && threadIdx.x == 0) *count_out_to_zero = 0u;   // the next k_shade appends to it
     const uint32_t count = *count_ptr;
     const uint32_t lane = threadIdx.x & 63u;
@@ -404,6 +412,20 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         __syncthreads();
         nodes = lds; spheres = lds + n4;
     }
+    const uint32_t top_bytes = TOP ? sc.n_top * 32u : 0u;
+    if (TOP) {
+        // the top of the tree: sc.n_top records, the same linear LDS-DMA copy
+        const float4* top = reinterpret_cast<const float4*>(sc.top_nodes);
+        const uint32_t tot = 2u * sc.n_top;
+        const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63u, nw = blockDim.x >> 6;
+        for (uint32_t base = wave * 64u; base < tot; base += nw * 64u) {
+            const uint32_t i = base + ln;
+            if (i < tot) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(top + i),
+                                                          (__attribute__((address_space(3))) void*)(lds + base), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     uint32_t w_next = min(wave_id * chunk, count), w_end = min(w_next + chunk, count);
     bool exhausted = false;
@@ -411,7 +433,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     bool have = false;
     // `node` is the BYTE offset of the lane's next node record; `pend` is 0 while the lane walks, else the leaf word it
     // waits with (or LEAF_IDLE / LEAF_DONE): one compare tells whether the lane takes part in a node step
-    const uint32_t end_off = n_nodes * kStride;
+    const uint32_t end_off = top_bytes + n_nodes * kStride;
     uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE, pend = rtd::LEAF_IDLE, from = 0;
     float tmax = kInf, tm = 0.f, a = 1.f;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
@@ -438,6 +460,19 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             typedef const __attribute__((address_space(3))) F4V* lds_f4;
             const F4V a0 = *reinterpret_cast<lds_f4>(off), a1 = *reinterpret_cast<lds_f4>(off + 16u);
             n0 = make_float4(a0.x, a0.y, a0.z, a0.w); n1 = make_float4(a1.x, a1.y, a1.z, a1.w);
+        } else if constexpr (TOP) {
+            // every lane reads LDS (a lane outside the top reads slot 0 and drops it); lanes outside the top load from HBM
+            typedef float F4V __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(3))) F4V* lds_f4;
+            const bool in_top = off < top_bytes;
+            const uint32_t lo = in_top ? off : 0u;
+            const F4V a0 = *reinterpret_cast<lds_f4>(lo), a1 = *reinterpret_cast<lds_f4>(lo + 16u);
+            n0 = make_float4(a0.x, a0.y, a0.z, a0.w); n1 = make_float4(a1.x, a1.y, a1.z, a1.w);
+            if (!in_top) {
+                const char* p = reinterpret_cast<const char*>(nodes) + (off - top_bytes);
+                n0 = *reinterpret_cast<const float4*>(p);
+                n1 = *reinterpret_cast<const float4*>(p + 16u);
+            }
         } else {
             n0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off);
             n1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off + 16u);
@@ -517,7 +552,10 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #endif
             float4 n0, n1;
             load_record(off, n0, n1);
-            const uint32_t skip = __float_as_uint(n1.z), leaf = __float_as_uint(n1.w);
+            const uint32_t skip = __float_as_uint(n1.z), leafw = __float_as_uint(n1.w);
+            // M_TOP: an inner record (leaf type 0) keeps its hit link in the leaf word; a leaf record continues at `skip` either way
+            const bool inner = TOP ? (leafw >> 28) == 0u : false;
+            const uint32_t leaf = (TOP && inner) ? 0u : leafw;
             // Aabb::hit (aabb.rs:31-55, interval carried across axes), on (centre, half extent): 4 packed ops for x and y,
             // one packed FMA + add/sub for z. min3/max3 ignore a NaN operand (0*inf), which keeps the box — conservative,
             // like the reference. A record without a box has h = inf.
@@ -532,12 +570,12 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #ifdef RT_DEBUG_LONGWALK
             if (COUNT) dbg_steps += walk ? 1u : 0u;
 #endif
-            const uint32_t next = boxhit ? node + kStride : skip;
+            const uint32_t next = TOP ? ((boxhit && inner) ? leafw : skip) : (boxhit ? node + kStride : skip);
             node = walk ? next : node;
             pend = (walk && boxhit) ? leaf : pend;            // leaf == 0 for an inner node
         }
         // ---- rare events, outside the steps ----
-        if (pend == rtd::LEAF_DONE || (pend == 0u && node >= end_off)) {   // walked off the end: world.hit is done
+        if (pend == kDone || (pend == 0u && node >= end_off)) {   // walked off the end: world.hit is done
             pool.hit[slot] = make_uint2(__float_as_uint(tmax), hit_prim);
 #ifdef RT_DEBUG_LONGWALK
             if (COUNT && dbg_steps > 100000u) {
@@ -1210,18 +1248,29 @@ __global__ void __launch_bounds__(256) k_untile(const T* __restrict__ gathered, 
 // launchers
 // ------------------------------------------------------------------------------------------------
 // Persistent grid of k_extend = what is resident at once. Registers and the LDS copy of the scene both
-// limit it; a scene whose LDS copy is large (book-2 final: 65 KB) allows two workgroups per CU, and then
-// 512-thread workgroups keep twice the waves of 256-thread ones. The runtime's occupancy query decides.
-template <bool LDS, uint32_t FEAT, bool COUNT>
+// limit it; a scene whose LDS copy is large (book-2 final: 65 KB; the 64 KB top of a tree that does not fit) allows two workgroups
+// per CU, and then larger workgroups keep more waves. The runtime's occupancy query decides between the sizes compiled per mode.
+template <int MODE, uint32_t FEAT, bool COUNT, uint32_t TPB>
+static hipError_t launch_extend_g(uint32_t n_groups, size_t lds_bytes, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
+                                  uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
+    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, TPB>), dim3(n_groups), dim3(TPB), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
+    return hipGetLastError();
+}
+template <int MODE, uint32_t FEAT, bool COUNT>
 static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
-    const size_t lds_bytes = LDS ? (((size_t)sc.n_nodes + 2u) * rtd::NODE_STRIDE_LDS + (size_t)sc.n_spheres * 16u) : 0u;
+    const size_t lds_bytes = MODE == M_LDS ? (((size_t)sc.n_nodes + 2u) * rtd::NODE_STRIDE_LDS + (size_t)sc.n_spheres * 16u) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
+    // thread counts compiled for this mode: the small group always, the large one where a big LDS copy limits the groups per CU
+    constexpr uint32_t kSmall = MODE == M_TOP ? 2u * kExtendThreads : kExtendThreads, kBig = 2u * kSmall;
     static thread_local size_t cached_lds = ~(size_t)0; static thread_local int nb_small = 0, nb_big = 0;
     if (cached_lds != lds_bytes) {
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_small, k_extend<LDS, FEAT, COUNT, kExtendThreads>, (int)kExtendThreads, lds_bytes);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_small, k_extend<MODE, FEAT, COUNT, kSmall>, (int)kSmall, lds_bytes);
         if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_big, k_extend<LDS, FEAT, COUNT, 2u * kExtendThreads>, (int)(2u * kExtendThreads), lds_bytes);
-        if (e != hipSuccess) return e;
+        nb_big = 0;
+        if (MODE != M_HBM) {
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_big, k_extend<MODE, FEAT, COUNT, (MODE != M_HBM ? kBig : kSmall)>, (int)kBig, lds_bytes);
+            if (e != hipSuccess) return e;
+        }
         if (nb_small < 1) nb_small = 1;
 #ifdef RT_EXTEND_PER_CU_MAX
         nb_small = std::min(nb_small, RT_EXTEND_PER_CU_MAX); nb_big = std::min(nb_big, RT_EXTEND_PER_CU_MAX / 2);   // tuning builds only
@@ -1229,17 +1278,15 @@ static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, cons
         cached_lds = lds_bytes;
     }
     if (cfg.extend_geometry) { cfg.extend_geometry[0] = (uint32_t)nb_small; cfg.extend_geometry[1] = (uint32_t)nb_big; }
-    if (2 * nb_big > nb_small)
-        hipLaunchKernelGGL((k_extend<LDS, FEAT, COUNT, 2u * kExtendThreads>), dim3(cfg.n_cu * (uint32_t)nb_big), dim3(2u * kExtendThreads), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
-    else
-        hipLaunchKernelGGL((k_extend<LDS, FEAT, COUNT, kExtendThreads>), dim3(cfg.n_cu * (uint32_t)nb_small), dim3(kExtendThreads), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
-    return hipGetLastError();
+    if (MODE != M_HBM && 2 * nb_big > nb_small)
+        return launch_extend_g<MODE, FEAT, COUNT, (MODE != M_HBM ? kBig : kSmall)>(cfg.n_cu * (uint32_t)nb_big, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
+    return launch_extend_g<MODE, FEAT, COUNT, kSmall>(cfg.n_cu * (uint32_t)nb_small, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
 }
-template <bool LDS, uint32_t FEAT>
+template <int MODE, uint32_t FEAT>
 static hipError_t launch_extend_t(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, bool count, hipStream_t stream) {
-    return count ? launch_extend_c<LDS, FEAT, true>(cfg, sc, pool, rd, count_ptr, head, cz, counters, stream)
-                 : launch_extend_c<LDS, FEAT, false>(cfg, sc, pool, rd, count_ptr, head, cz, counters, stream);
+    return count ? launch_extend_c<MODE, FEAT, true>(cfg, sc, pool, rd, count_ptr, head, cz, counters, stream)
+                 : launch_extend_c<MODE, FEAT, false>(cfg, sc, pool, rd, count_ptr, head, cz, counters, stream);
 }
 
 // Kernel variants are compiled for a few feature sets; a scene runs on the smallest one that covers it.
@@ -1258,10 +1305,12 @@ static uint32_t pick_variant(uint32_t need) {
 hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                          uint32_t* head, uint32_t* cz, unsigned long long* counters, bool count, hipStream_t stream) {
     const uint32_t v = pick_variant(cfg.features);
-#define RT_EXT(LDSV, F) launch_extend_t<LDSV, F>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream)
-    if (cfg.scene_in_lds)
-        return v == 0u ? RT_EXT(true, 0u) : v == kVariantMesh ? RT_EXT(true, kVariantMesh) : v == kVariantBox ? RT_EXT(true, kVariantBox) : RT_EXT(true, F_ALL);
-    return v == 0u ? RT_EXT(false, 0u) : v == kVariantMesh ? RT_EXT(false, kVariantMesh) : v == kVariantBox ? RT_EXT(false, kVariantBox) : RT_EXT(false, F_ALL);
+#define RT_EXT(M, F) launch_extend_t<M, F>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream)
+#define RT_EXT_V(M) (v == 0u ? RT_EXT(M, 0u) : v == kVariantMesh ? RT_EXT(M, kVariantMesh) : v == kVariantBox ? RT_EXT(M, kVariantBox) : RT_EXT(M, F_ALL))
+    if (cfg.scene_in_lds) return RT_EXT_V(M_LDS);
+    if (sc.n_top != 0u) return RT_EXT_V(M_TOP);
+    return RT_EXT_V(M_HBM);
+#undef RT_EXT_V
 #undef RT_EXT
 }
 

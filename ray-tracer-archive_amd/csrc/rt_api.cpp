@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <limits>
@@ -157,6 +158,51 @@ static std::vector<unsigned char> device_nodes(const std::vector<rtd::Node>& nod
     std::memcpy(out.data() + (nodes.size() + 1) * stride, &end, sizeof(end));
     return out;
 }
+// Layout for a scene that does not fit LDS as a whole (device_types.h: LEAF_DONE_TOP): the array in HBM plus a copy of the TOP of
+// the tree for LDS. The top = every record above a depth cut (depth = number of enclosing subtrees [i, skip_i) in the threaded
+// array), the deepest cut with at most `max_top` records — so it is closed under "parent of", a walk starts in it, and whenever a
+// `skip` leads back up it re-enters it. Returns false when there is nothing to gain (no cut fits) or the address space is too small.
+struct TopLayout { std::vector<unsigned char> hbm, top; uint32_t n_top = 0; };
+static bool device_nodes_top(const std::vector<rtd::Node>& nodes, uint32_t max_top, TopLayout& out) {
+    const size_t n = nodes.size();
+    if (n == 0 || max_top == 0) return false;
+    std::vector<uint32_t> depth(n), per_depth;
+    {
+        std::vector<uint32_t> ends;
+        for (size_t i = 0; i < n; ++i) {
+            while (!ends.empty() && ends.back() <= i) ends.pop_back();
+            depth[i] = (uint32_t)ends.size();
+            if (depth[i] >= per_depth.size()) per_depth.resize(depth[i] + 1, 0u);
+            per_depth[depth[i]]++;
+            if (nodes[i].skip > i + 1) ends.push_back(nodes[i].skip);
+        }
+    }
+    uint32_t cut = 0; uint64_t total = 0;
+    while (cut < per_depth.size() && total + per_depth[cut] <= max_top) total += per_depth[cut++];
+    if (cut == 0 || total == n) return false;          // (a scene whose every record fits is LDS-resident as a whole already)
+    const uint32_t n_top = (uint32_t)total, top_bytes = n_top * 32u;
+    if ((uint64_t)top_bytes + (n + 2) * 32ull >= rtd::TOP_SPACE_BYTES) return false;
+    std::vector<uint32_t> slot(n, 0xFFFFFFFFu);
+    { uint32_t k = 0; for (size_t i = 0; i < n; ++i) if (depth[i] < cut) slot[i] = k++; }
+    auto U = [&](size_t i) -> uint32_t { return (i < n && slot[i] != 0xFFFFFFFFu) ? slot[i] * 32u : top_bytes + (uint32_t)i * 32u; };
+    const std::vector<unsigned char> plain = device_nodes(nodes, 32);     // boxes as (centre, half extent), padded: reuse
+    out.hbm.assign(plain.begin(), plain.end());
+    out.top.assign((size_t)n_top * 32, 0);
+    for (size_t i = 0; i < n; ++i) {
+        rtd::NodeDev d; std::memcpy(&d, plain.data() + i * 32, 32);
+        d.skip_bytes = U(nodes[i].skip);
+        d.leaf = nodes[i].leaf != 0u ? nodes[i].leaf : U(i + 1);          // inner record: the hit link
+        std::memcpy(out.hbm.data() + i * 32, &d, 32);
+        if (slot[i] != 0xFFFFFFFFu) std::memcpy(out.top.data() + (size_t)slot[i] * 32, &d, 32);
+    }
+    for (size_t k = n; k < n + 2; ++k) {                                   // closing record (twice, as in the plain layout)
+        rtd::NodeDev d; std::memcpy(&d, plain.data() + k * 32, 32);
+        d.skip_bytes = U(n); d.leaf = rtd::LEAF_DONE_TOP;
+        std::memcpy(out.hbm.data() + k * 32, &d, 32);
+    }
+    out.n_top = n_top;
+    return true;
+}
 static size_t lds_scene_bytes(const rtc::CompiledScene& cs) { return (cs.nodes.size() + 2) * (size_t)rtd::NODE_STRIDE_LDS + cs.spheres.size() * 16; }
 
 int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
@@ -171,7 +217,16 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     int r = RT_OK;
     auto up = [&](auto& buf, const auto& vec) { if (r == RT_OK) r = upload(ctx, buf, vec); };
     const bool in_lds = lds_scene_bytes(cs) <= kLdsSceneBudget;
-    const std::vector<unsigned char> dnodes = device_nodes(cs.nodes, in_lds ? rtd::NODE_STRIDE_LDS : rtd::NODE_STRIDE_HBM);   // alive until the stream sync below
+    std::vector<unsigned char> dnodes;   // alive until the stream sync below
+    TopLayout tl;
+    // RT_TOP_NODES: records of the top of the tree kept in LDS for scenes that do not fit (0 = none; 2048 = 64 KB leaves two
+    // 1024-thread workgroups per CU, i.e. the full 32 waves)
+    uint32_t max_top = 2048u;
+    if (const char* e = getenv("RT_TOP_NODES")) max_top = (uint32_t)std::strtoul(e, nullptr, 10);
+    max_top = std::min<uint32_t>(max_top, (160u * 1024u) / 32u);
+    const bool top = !in_lds && device_nodes_top(cs.nodes, max_top, tl);
+    if (top) { dnodes.swap(tl.hbm); up(s->top_nodes, tl.top); }
+    else dnodes = device_nodes(cs.nodes, in_lds ? rtd::NODE_STRIDE_LDS : rtd::NODE_STRIDE_HBM);
     up(s->nodes, dnodes); up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
     up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->media, cs.media);
     up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
@@ -180,6 +235,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     if (r != RT_OK) { rt_scene_destroy(ctx, s); return r; }
     rtk::SceneDev& d = s->dev;
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
+    d.top_nodes = top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = top ? tl.n_top : 0u;
     d.n_prim_kinds = (cs.sphere_meta.empty() ? 0u : 1u) + (cs.moving_meta.empty() ? 0u : 1u) + (cs.rect_meta.empty() ? 0u : 1u) +
                      (cs.tri_meta.empty() ? 0u : 1u) + (cs.media.empty() ? 0u : 1u);
     d.spheres = (const rtd::Float4*)s->spheres.p; d.sphere_meta = (const uint32_t*)s->sphere_meta.p; d.n_spheres = (uint32_t)cs.spheres.size();
@@ -378,7 +434,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         for (int k = 0; k < 5; ++k) stats->debug[k] = ctx->h_counters[rtk::CTR_DEBUG + k];
         stats->debug[6] = extend_geometry[0]; stats->debug[7] = extend_geometry[1];   // resident k_extend groups per CU (256 / 512 threads)
         stats->iterations = (uint32_t)ctx->h_counters[rtk::CTR_ITERATIONS]; stats->extend_launches = launched; stats->shade_launches = launched; stats->pool_slots = P;
-        stats->n_devices = 1u;
+        stats->n_devices = 1u; stats->lds_top_nodes = scene->dev.n_top;
         stats->scene_nodes = scene->n_nodes; stats->scene_prims = scene->n_prims; stats->scene_bytes = scene->bytes; stats->bvh_in_lds = scene->in_lds ? 1u : 0u;
     }
     return RT_OK;
@@ -432,6 +488,42 @@ int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out) {
     out->n_lights = cs.lights.size(); out->n_materials = cs.mat_b.size();
     out->features = scene_features(cs);
     out->fits_lds = lds_scene_bytes(cs) <= kLdsSceneBudget ? 1u : 0u;
+    return RT_OK;
+}
+
+int rt_scene_top_layout_check(const RtSceneDesc* desc, uint32_t max_top, uint64_t* out_n_top) {
+    if (!desc) return set_err(nullptr, RT_ERR_INVALID, "null argument");
+    rtc::CompiledScene cs;
+    const int rc = rtc::compile_scene(*desc, cs);
+    if (rc != RT_OK) return set_err(nullptr, rc, "scene: " + cs.error);
+    TopLayout tl;
+    if (out_n_top) *out_n_top = 0;
+    if (!device_nodes_top(cs.nodes, max_top, tl)) return RT_OK;        // no top: nothing to check
+    if (out_n_top) *out_n_top = tl.n_top;
+    const size_t n = cs.nodes.size();
+    const uint32_t top_bytes = tl.n_top * 32u;
+    auto rec = [&](uint32_t addr) -> rtd::NodeDev {
+        rtd::NodeDev d;
+        std::memcpy(&d, addr < top_bytes ? tl.top.data() + addr : tl.hbm.data() + (addr - top_bytes), 32);
+        return d;
+    };
+    // unified address of every record, found by the walk that "hits" every box: it must enumerate the records in pre-order
+    std::vector<uint32_t> addr(n + 1);
+    uint32_t a = 0;
+    for (size_t i = 0; i < n; ++i) {
+        addr[i] = a;
+        const rtd::NodeDev d = rec(a);
+        const rtd::NodeDev h = rec(top_bytes + (uint32_t)i * 32u);
+        if (std::memcmp(&d, &h, 32) != 0) return set_err(nullptr, RT_ERR_DEVICE, "top copy differs from the HBM record");
+        if (cs.nodes[i].leaf != 0u ? d.leaf != cs.nodes[i].leaf : (d.leaf >> 28) != 0u) return set_err(nullptr, RT_ERR_DEVICE, "leaf word");
+        a = (d.leaf >> 28) == 0u ? d.leaf : d.skip_bytes;
+    }
+    addr[n] = a;
+    if (a != top_bytes + (uint32_t)n * 32u || rec(a).leaf != rtd::LEAF_DONE_TOP || rec(a).skip_bytes != a) return set_err(nullptr, RT_ERR_DEVICE, "closing record");
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t want = addr[std::min<size_t>(cs.nodes[i].skip, n)];
+        if (rec(addr[i]).skip_bytes != want) return set_err(nullptr, RT_ERR_DEVICE, "skip link of record " + std::to_string(i));
+    }
     return RT_OK;
 }
 

@@ -231,3 +231,28 @@ def test_sah_tree_is_a_valid_accelerator(pkg, orc):
             total += v
         visits[builder] = total
     assert visits[A.RT_BVH_SAH] < 0.8 * visits[A.RT_BVH_REFERENCE]
+
+
+def test_top_of_tree_layout(pkg):
+    """Scenes that do not fit LDS keep the top of the tree there (kernels.hip M_TOP): the linked two-memory layout is checked on the host
+    for a sphere BVH, a mixed scene with instance wrappers (ENTER/EXIT records) and media, and several sizes of the top."""
+    import ctypes as C
+    L = pkg.lib()
+
+    def check(desc, max_top):
+        n = C.c_uint64(0)
+        rc = L.rt_scene_top_layout_check(C.byref(desc), max_top, C.byref(n))
+        assert rc == 0, L.rt_last_error(None)
+        return n.value
+    big = pkg.HostScene("big", 5, 20000, 32)
+    info = pkg.compile_info(big.desc)
+    tops = [check(big.desc, k) for k in (1, 7, 64, 2048, 5000)]
+    assert tops[0] == 1 and all(0 < t <= k for t, k in zip(tops, (1, 7, 64, 2048, 5000))) and tops == sorted(tops)
+    assert check(big.desc, info["n_nodes"] + 10) == 0                 # everything fits: no top is built
+    sah = pkg.HostScene("big_sah", 5, 20000, 32)
+    assert 0 < check(sah.desc, 2048) <= 2048
+    # wrappers, lists, media: records without boxes and ENTER/EXIT pairs are ordinary records of the walk
+    for name in ("final", "cornell_smoke", "book1_ref"):
+        hs = pkg.HostScene(name, 1)
+        for k in (3, 50, 400):
+            check(hs.desc, k)
