@@ -37,30 +37,18 @@ inline uint32_t make_leaf(uint32_t type, uint32_t first, uint32_t count) { retur
 // A node without a box (list members, wrappers) stores mn.x = -inf: the slab test passes and the
 // node is not counted as an Aabb::hit.
 //
-// The DEVICE copy of the array (rt_api.cpp: device_nodes) holds the same records regrouped for the
-// kernel, boxes as centre c and half extent h: a = (c.x, c.y, h.x, h.y), b = (c.z, h.z, skip * stride, leaf).
-// A ray meets an axis' slab at tc -+ th (tc = c/d - o/d, th = h/|d|): no min/max to order the planes, and
-// one visit is two packed FMAs, a packed multiply and two packed adds; `skip` is already the byte offset
-// of the next record. h is rounded up and padded so that [c-h, c+h] contains the (padded) host box; a
-// record without a box has c = 0, h = inf. One extra
-struct NodeDev { float cx, cy, hx, hy, cz, hz; uint32_t skip_bytes, leaf; };
+// The DEVICE copy of the array (rt_api.cpp: device_nodes, which documents the address space) holds the same records regrouped for
+// the kernel, boxes as centre c and half extent h: a = (c.x, c.y, h.x, h.y), b = (c.z, h.z, skip, hit). A ray meets an axis' slab at
+// tc -+ th (tc = c/d - o/d, th = h/|d|): no min/max to order the planes, and one visit is two packed FMAs, a packed multiply and two
+// packed adds. h is rounded up and padded so that [c-h, c+h] contains the (padded) host box; a record without a box has c = 0,
+// h = inf. `skip` and `hit` are the byte addresses of the record the walk visits next when the box is missed / passed: a lane's whole
+// state is its address. `hit` of a record with a leaf payload is that leaf's PARK TWIN (a record whose box cannot be passed and whose
+// links lead to itself; its first two words are the address to resume at and the leaf payload); DONE and IDLE are such records too.
+struct NodeDev { float cx, cy, hx, hy, cz, hz; uint32_t skip_bytes, leaf /* = hit link */; };
 static_assert(sizeof(NodeDev) == 32, "device node record is 32 bytes");
-// Record stride: packed, in HBM and in LDS. (48-byte records in LDS halve the ds_read_b128 bank conflicts of lanes at
-// different nodes — 32-byte records only reach 8 of the 16 slot columns — but measured no faster: the visit is bound
-// by VALU issue, and the larger copy pushed the book-2 scene out of LDS. -DRT_NODE_STRIDE_LDS=48 keeps the experiment.)
-#ifndef RT_NODE_STRIDE_LDS
-#define RT_NODE_STRIDE_LDS 32
-#endif
-constexpr uint32_t NODE_STRIDE_HBM = 32, NODE_STRIDE_LDS = RT_NODE_STRIDE_LDS;
-// lane states of k_extend kept in the `pend` word (leaf type 0 = no primitive work):
+// payload words of the two shared self-loop records (leaf type 0 = no primitive work):
 constexpr uint32_t LEAF_IDLE = 1u << 24;   // the lane holds no ray
 constexpr uint32_t LEAF_DONE = 2u << 24;   // the lane's ray has visited every node
-// Layout with the top of the tree in LDS (kernels.hip M_TOP; rt_api.cpp device_nodes_top): `skip_bytes` and, for an inner record
-// (leaf type 0), the leaf word are addresses in ONE space: [0, top_bytes) = the record's slot in the LDS copy of the top,
-// top_bytes + 32 * i = record i of the HBM array. A record with a leaf payload continues at `skip_bytes` (its subtree is itself).
-// Hit links live in the 28 low bits of the leaf word, so the space is 256 MB (8 M records); larger scenes stay in HBM alone.
-constexpr uint32_t LEAF_DONE_TOP = 15u << 28;   // leaf word of the closing record in that layout
-constexpr uint32_t TOP_SPACE_BYTES = 1u << 28;
 
 // ---- primitives: one geometry array per type (16-byte records) + one u32 `meta` per primitive ----
 // meta = material id (22 bits) | wrap id << 22 (10 bits)

@@ -20,6 +20,7 @@ enum : uint32_t { CTR_NODE_TESTS = 0, CTR_PRIM_TESTS = 1, CTR_SAMPLES = 7, CTR_D
 struct SceneDev {
     const rtd::Float4* nodes; uint32_t n_nodes;
     const rtd::Float4* top_nodes; uint32_t n_top;   // top of the tree staged in LDS when the scene does not fit (0: none)
+    uint32_t n_records;      // records of `nodes` in all: n_nodes + DONE + IDLE + one park twin per leaf (device_types.h)
     uint32_t n_prim_kinds;   // how many of {sphere, moving sphere, rect, triangle, medium} the scene holds
     const rtd::Float4* spheres; const uint32_t* sphere_meta; uint32_t n_spheres;
     const rtd::Float4* moving; const uint32_t* moving_meta;

@@ -360,16 +360,20 @@ constexpr uint32_t kChunk = RT_CHUNK;
 constexpr int kSteps = RT_STEPS;
 constexpr int kLeafBatch = RT_LEAF_BATCH;
 
-// Lane-level state machine: a lane with a ray either walks nodes (pend == 0) or waits with a leaf whose
-// primitives are still to be tested (pend = the node's leaf word). Node visits and primitive tests run
-// in separate passes so that each pass keeps many lanes busy: a primitive test (f64 refinement) costs
-// several node visits, and in lock step with node visits it would run with one or two active lanes.
-// Per lane the ORDER of events is unchanged: the leaf is tested before the lane visits its next node.
-// MODE: where the node records live. M_HBM: the array in HBM (L2 / Infinity Cache). M_LDS: the whole scene (nodes + spheres) staged in
-// LDS. M_TOP: the scene does not fit, so the TOP of the tree (every node above a depth cut, rt_api.cpp: device_nodes_top) is staged
-// in LDS and the rest stays in HBM; one address space covers both (offsets below top_bytes are LDS slots, the others HBM offsets
-// + top_bytes), every record carries its own links in that space (`skip`, and for an inner node the hit link in the leaf word),
-// so a walk moves between the two memories without knowing it.
+// Lane-level state machine. A lane's whole traversal state is the ADDRESS of the record it visits next (device_types.h NodeDev,
+// rt_api.cpp device_nodes): every record names both successors — `hit` when its box is passed, `skip` when not — so a node visit is
+// two 16-byte reads, the slab test and ONE select, for every lane alike, with no "is this lane walking" test. A lane that passes a
+// leaf's box lands on that leaf's park twin, a record that leads back to itself; a lane whose walk ran off the end sits on DONE,
+// a lane without a ray on IDLE. Between groups of kSteps visits the wave looks at the addresses: DONE lanes store their hit,
+// parked lanes wait for the primitive pass, which runs when enough of them hold a leaf. Node visits and primitive tests thus run
+// in separate passes, each with many lanes busy (a primitive test with its f64 refinement costs several node visits; in lock step
+// with the visits it would run with one or two active lanes). Per lane the ORDER of events is the reference's: the leaf is tested
+// before the lane visits the record after it.
+//
+// MODE: where the records live. M_LDS: the whole scene (records + sphere data) staged in LDS. M_HBM: the array in HBM (L2 /
+// Infinity Cache). M_TOP: the scene does not fit, so the TOP of the tree (rt_api.cpp: every record above a depth cut) is staged in
+// LDS and the rest stays in HBM; addresses below top_bytes are LDS slots, the others HBM offsets + top_bytes, and since every
+// record carries its links in that one space a walk moves between the two memories without knowing it.
 enum : int { M_HBM = 0, M_LDS = 1, M_TOP = 2 };
 template <int MODE, uint32_t FEAT, bool COUNT, uint32_t TPB>
 __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
@@ -377,8 +381,6 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                                                  unsigned long long* __restrict__ counters, RenderDev rd) {
     extern __shared__ float4 lds[];
     constexpr bool LDS = MODE == M_LDS, TOP = MODE == M_TOP;
-    constexpr uint32_t kStride = LDS ? rtd::NODE_STRIDE_LDS : rtd::NODE_STRIDE_HBM;   // bytes per node record (device_types.h)
-    constexpr uint32_t kDone = TOP ? rtd::LEAF_DONE_TOP : rtd::LEAF_DONE;              // leaf word of the closing record
     if (blockIdx.x == 0 && threadIdx.x == 0) *count_out_to_zero = 0u;   // the next k_shade appends to it
     const uint32_t count = *count_ptr;
     const uint32_t lane = threadIdx.x & 63u;
@@ -391,50 +393,35 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     // Short queue (the long tail of a render, hundreds of launches with a few thousand rays): a workgroup whose
     // waves own no static chunk has no dynamic chunk to fetch either — leave before staging the scene.
     if (blockIdx.x * (blockDim.x >> 6) * chunk >= count && head0 >= count) return;
-    const uint32_t n_nodes = sc.n_nodes;
     const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
     const float4* spheres = reinterpret_cast<const float4*>(sc.spheres);
-    if (LDS) {
-        // stage the node records and the sphere records (the whole BVH for book-1-sized scenes): a linear
-        // copy, i.e. exactly the shape of LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, LDS
-        // address = wave base + lane * 16, no VGPR round trip); all pieces in flight, then one wait + barrier
-        const uint32_t n4 = (kStride / 16u) * (n_nodes + 2u), s4 = sc.n_spheres, tot = n4 + s4;   // nodes (+ closing record + pad) then spheres, contiguous in LDS
+    const uint32_t top_bytes = TOP ? sc.n_top * 32u : 0u;
+    if (LDS || TOP) {
+        // stage the records (M_LDS: all of them, then the sphere data; M_TOP: the top of the tree): a linear copy, i.e. exactly the
+        // shape of LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, LDS address = wave base + lane * 16, no VGPR round
+        // trip); all pieces in flight, then one wait + barrier
+        const float4* src0 = LDS ? nodes : reinterpret_cast<const float4*>(sc.top_nodes);
+        const uint32_t n4 = 2u * (LDS ? sc.n_records : sc.n_top), s4 = LDS ? sc.n_spheres : 0u, tot = n4 + s4;
         const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63u, nw = blockDim.x >> 6;
         for (uint32_t base = wave * 64u; base < tot; base += nw * 64u) {
             const uint32_t i = base + ln;
             if (i < tot) {
-                const float4* src = i < n4 ? nodes + i : spheres + (i - n4);
+                const float4* src = i < n4 ? src0 + i : spheres + (i - n4);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(lds + base), 16, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        nodes = lds; spheres = lds + n4;
+        if (LDS) { nodes = lds; spheres = lds + n4; }
     }
-    const uint32_t top_bytes = TOP ? sc.n_top * 32u : 0u;
-    if (TOP) {
-        // the top of the tree: sc.n_top records, the same linear LDS-DMA copy
-        const float4* top = reinterpret_cast<const float4*>(sc.top_nodes);
-        const uint32_t tot = 2u * sc.n_top;
-        const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63u, nw = blockDim.x >> 6;
-        for (uint32_t base = wave * 64u; base < tot; base += nw * 64u) {
-            const uint32_t i = base + ln;
-            if (i < tot) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(top + i),
-                                                          (__attribute__((address_space(3))) void*)(lds + base), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
+    // the three kinds of self-loop records, by address (device_nodes): DONE, IDLE, then the park twins
+    const uint32_t special = top_bytes + sc.n_nodes * 32u, a_done = special, a_idle = special + 32u, a_twins = special + 64u;
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     uint32_t w_next = min(wave_id * chunk, count), w_end = min(w_next + chunk, count);
     bool exhausted = false;
 
-    bool have = false;
-    // `node` is the BYTE offset of the lane's next node record; `pend` is 0 while the lane walks, else the leaf word it
-    // waits with (or LEAF_IDLE / LEAF_DONE): one compare tells whether the lane takes part in a node step
-    const uint32_t end_off = top_bytes + n_nodes * kStride;
-    uint32_t slot = 0, node = 0, hit_prim = rtd::HIT_NONE, pend = rtd::LEAF_IDLE, from = 0;
+    uint32_t slot = 0, node = a_idle, hit_prim = rtd::HIT_NONE, from = 0;
     float tmax = kInf, tm = 0.f, a = 1.f;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
     SlabRay sr; sr.inv_xy = sr.noi_xy = sr.ainv_xy = sr.inv_z = sr.noi_z = F2{0.f, 0.f};
@@ -451,19 +438,18 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #else
 #define STAMP(x)
 #endif
-    // the two halves of the node record at byte offset `off`
+    typedef float F4V __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) F4V* lds_f4;
+    typedef uint32_t U2V __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(3))) U2V* lds_u2;
+    // the two halves of the record at address `off`
     auto load_record = [&](uint32_t off, float4& n0, float4& n1) {
         if constexpr (LDS) {
-            // k_extend has no static LDS, so the staged copy starts at LDS address 0: the record's offset IS its address
-            // (saves the add of a link-time base per visit; the staging loop above writes through `lds`, the same bytes)
-            typedef float F4V __attribute__((ext_vector_type(4)));
-            typedef const __attribute__((address_space(3))) F4V* lds_f4;
+            // k_extend has no static LDS, so the staged copy starts at LDS address 0: the record's address IS its LDS address
             const F4V a0 = *reinterpret_cast<lds_f4>(off), a1 = *reinterpret_cast<lds_f4>(off + 16u);
             n0 = make_float4(a0.x, a0.y, a0.z, a0.w); n1 = make_float4(a1.x, a1.y, a1.z, a1.w);
         } else if constexpr (TOP) {
             // every lane reads LDS (a lane outside the top reads slot 0 and drops it); lanes outside the top load from HBM
-            typedef float F4V __attribute__((ext_vector_type(4)));
-            typedef const __attribute__((address_space(3))) F4V* lds_f4;
             const bool in_top = off < top_bytes;
             const uint32_t lo = in_top ? off : 0u;
             const F4V a0 = *reinterpret_cast<lds_f4>(lo), a1 = *reinterpret_cast<lds_f4>(lo + 16u);
@@ -478,24 +464,30 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             n1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + off + 16u);
         }
     };
+    // (resume address, leaf payload) of the park twin at `off` (twins are never part of the top)
+    auto load_twin = [&](uint32_t off) -> uint2 {
+        if constexpr (LDS) { const U2V v = *reinterpret_cast<lds_u2>(off); return make_uint2(v.x, v.y); }
+        else return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(nodes) + (off - top_bytes));
+    };
     // One outer iteration = one refill. The ray records of the next 64 queue slots are loaded into No/Nd at
     // the END of a refill (one unconditional definition per iteration, so hipcc keeps the loads in flight) and
     // handed out at the NEXT refill by __shfl (ds_bpermute): the wave no longer parks on HBM latency with
-    // its other lanes' rays stalled. Only the chunk atomic (once per 256 rays) is still waited for in place.
+    // its other lanes' rays stalled. Only the chunk atomic (once per chunk) is still waited for in place.
     Float4 No = Float4{0, 0, 0, 0}, Nd = Float4{0, 0, 1, 0};
     uint32_t n_cnt = 0;                // valid prefetched entries: slots [w_next, w_next + n_cnt)
     for (;;) {
         STAMP(st_a);
         // ---- refill: idle lanes take prefetched rays (ballot + prefix rank) ----
         {
-            const uint64_t idle = __ballot(!have);
+            const bool is_idle = node == a_idle;
+            const uint64_t idle = __ballot(is_idle);
             const uint32_t take = min((uint32_t)__popcll(idle), n_cnt);
             if (take != 0u) {
                 const uint32_t rank = lane_rank(idle);
                 const int src = (int)(rank & 63u);
                 const float ox = __shfl(No.x, src), oy = __shfl(No.y, src), oz = __shfl(No.z, src), ot = __shfl(No.w, src);
                 const float dx = __shfl(Nd.x, src), dy = __shfl(Nd.y, src), dz = __shfl(Nd.z, src), dfrom = __shfl(Nd.w, src);
-                if (!have && rank < take) {
+                if (is_idle && rank < take) {
                     slot = w_next + rank;
                     o = v3(ox, oy, oz); d = v3(dx, dy, dz); tm = ot;
                     from = __float_as_uint(dfrom);            // primitive this ray starts on (0: camera / medium)
@@ -507,13 +499,13 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                         seg = sd & 0xFFu;
                         mkey = path_base(rd.seed, (uint64_t)(xy >> 16) * rd.width + (xy & 0xFFFFu), sd >> 8);
                     }
-                    tmax = kInf; node = 0; hit_prim = rtd::HIT_NONE; pend = 0; have = true;
+                    tmax = kInf; node = 0u; hit_prim = rtd::HIT_NONE;   // address 0 = the root (the first record, or its copy in the top)
                 }
                 w_next += take;
             }
             if (!exhausted && w_next == w_end) {
                 // guided self-scheduling: full chunks while the queue is long, smaller ones near its end so
-                // that the last waves to finish hold 64 rays, not 256 (one atomic per chunk either way)
+                // that the last waves to finish hold 64 rays, not a whole chunk (one atomic per chunk either way)
                 uint32_t start = 0;
                 if (lane == 0u) start = atomicAdd(head, chunk);
                 start = first_lane_u32(start) + head0;
@@ -529,7 +521,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             const uint32_t idx = n_cnt != 0u ? w_next + min(lane, n_cnt - 1u) : 0u;
             No = pool.ray_o[idx]; Nd = pool.ray_d[idx];
         }
-        if (__ballot(have) == 0ull && n_cnt == 0u) break;       // queue empty, nothing in flight
+        if (__ballot(node != a_idle) == 0ull && n_cnt == 0u) break;       // queue empty, nothing in flight
 #ifdef RT_STAMPS
         STAMP(st_b); st_refill += st_b - st_a;
 #endif
@@ -538,44 +530,28 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #ifdef RT_STAMPS
         STAMP(st_b);
 #endif
-        // ---- node pass: branch-free steps. A lane that is not walking (no ray, holding a leaf, done) re-reads
-        // record 0 and keeps its state; everything is a select: ~22 VALU, two ds_read_b128, no exec-mask traffic.
-        // The array ends with a box-less record that skips to itself and carries LEAF_DONE, so a lane that walks off
-        // the end parks by itself. Boxes carry the rounding slack of this test (scene_compile.cpp: pad_scale). ----
+        // ---- node pass: kSteps visits, every lane, no exec-mask traffic: two 16-byte reads, 5 packed + 8 plain VALU, one select ----
 #pragma unroll
         for (int step = 0; step < kSteps; ++step) {
-            const bool walk = pend == 0u;
-#ifdef RT_PARK_READS_ROOT
-            const uint32_t off = walk ? node : 0u;
-#else
-            const uint32_t off = node;      // a parked lane re-reads its own next record (an idle one record 0) and ignores it
-#endif
             float4 n0, n1;
-            load_record(off, n0, n1);
-            const uint32_t skip = __float_as_uint(n1.z), leafw = __float_as_uint(n1.w);
-            // M_TOP: an inner record (leaf type 0) keeps its hit link in the leaf word; a leaf record continues at `skip` either way
-            const bool inner = TOP ? (leafw >> 28) == 0u : false;
-            const uint32_t leaf = (TOP && inner) ? 0u : leafw;
+            load_record(node, n0, n1);
             // Aabb::hit (aabb.rs:31-55, interval carried across axes), on (centre, half extent): 4 packed ops for x and y,
             // one packed FMA + add/sub for z. min3/max3 ignore a NaN operand (0*inf), which keeps the box — conservative,
-            // like the reference. A record without a box has h = inf.
+            // like the reference. A record without a box has h = inf; a self-loop record has h < 0 and both links on itself.
             const F2 tc = __builtin_elementwise_fma(F2{n0.x, n0.y}, sr.inv_xy, sr.noi_xy);   // (tcx, tcy)
             const F2 th = F2{n0.z, n0.w} * sr.ainv_xy;                                         // (thx, thy)
             const F2 tz = __builtin_elementwise_fma(F2{n1.x, n1.y}, sr.inv_z, sr.noi_z);      // (tcz, thz)
             const F2 lo = tc - th, hi = tc + th;
             const float tnear = fmaxf(fmaxf(lo.x, lo.y), fmaxf(tz.x - tz.y, kTMin));
             const float tfar = fminf(fminf(hi.x, hi.y), fminf(tz.x + tz.y, tmax));
-            const bool boxhit = tnear <= tfar;
-            if (COUNT) c_nodes += (walk && n0.z < kInf) ? 1ull : 0ull;
+            if (COUNT) c_nodes += (node < special && n0.z < kInf) ? 1ull : 0ull;
 #ifdef RT_DEBUG_LONGWALK
-            if (COUNT) dbg_steps += walk ? 1u : 0u;
+            if (COUNT) dbg_steps += node < special ? 1u : 0u;
 #endif
-            const uint32_t next = TOP ? ((boxhit && inner) ? leafw : skip) : (boxhit ? node + kStride : skip);
-            node = walk ? next : node;
-            pend = (walk && boxhit) ? leaf : pend;            // leaf == 0 for an inner node
+            node = tnear <= tfar ? __float_as_uint(n1.w) : __float_as_uint(n1.z);             // hit : skip
         }
-        // ---- rare events, outside the steps ----
-        if (pend == kDone || (pend == 0u && node >= end_off)) {   // walked off the end: world.hit is done
+        // ---- events, outside the steps: lanes on a self-loop record ----
+        if (node == a_done) {                                                // walked off the end: world.hit is done
             pool.hit[slot] = make_uint2(__float_as_uint(tmax), hit_prim);
 #ifdef RT_DEBUG_LONGWALK
             if (COUNT && dbg_steps > 100000u) {
@@ -587,17 +563,21 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             }
             dbg_steps = 0u;
 #endif
-            have = false; pend = rtd::LEAF_IDLE; node = 0u;
+            node = a_idle;
         }
+        // leaf payload of a parked lane (0 for the others)
+        uint32_t pend = 0u, resume = 0u;
+        const bool parked = node >= a_twins;
+        if (parked) { const uint2 tw = load_twin(node); resume = tw.x; pend = tw.y; }
         if (FEAT & F_XFORM) {
             const uint32_t type = pend >> 28;
-            if (type == rtd::LT_ENTER || type == rtd::LT_EXIT) {   // Translate/RotateY::hit: switch ray space
+            if (type == rtd::LT_ENTER || type == rtd::LT_EXIT) {   // Translate/RotateY::hit: switch ray space, move on
                 const uint32_t xf = pend & rtd::LEAF_MAX_FIRST;
                 if (xf == 0u) { o = ow; d = dw; }
                 else xform_ray(sc.xforms[xf], ow, dw, o, d);
                 set_slab_ray(o, d, sr);
                 if (COUNT) { if (type == rtd::LT_ENTER) c_prims[5]++; }
-                pend = 0u;
+                pend = 0u; node = resume;
             }
         }
 #ifdef RT_STAMPS
@@ -605,8 +585,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         STAMP(st_a); st_node += st_a - st_b;
 #endif
         // ---- primitive pass: when enough lanes hold a leaf, or nobody can walk any further ----
-        const uint64_t pm = __ballot((pend >> 28) != 0u);
-        const bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(pend == 0u) == 0ull);
+        const uint64_t pm = __ballot(pend != 0u);
+        const bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(node < special) == 0ull);
         // Scenes with four or more primitive kinds (book-2 final: spheres, a moving sphere, rects, media): a pass serves ONE
         // kind, the one most lanes wait with; the others stay parked and win a later pass. Every kind's code then runs with
         // as many lanes as the wave can give it instead of several kinds back to back with a handful of lanes each
@@ -622,9 +602,9 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                 if (c > best) { best = c; serve = k; }
             }
         }
-        if (do_prims && (pend >> 28) != 0u && (serve == 0u || (pend >> 28) == serve)) {
+        if (do_prims && pend != 0u && (serve == 0u || (pend >> 28) == serve)) {
             const uint32_t type = pend >> 28, cnt = (pend >> 24) & 15u, first = pend & rtd::LEAF_MAX_FIRST;
-            pend = 0u;
+            node = resume;                                        // the record after the leaf, once its primitives are tested
             if (type == rtd::LT_SPHERE) {
                 // two phases, so that the f64 refinement (several times the cost of the filter) runs once per SURVIVOR
                 // of the wave's slowest lane, not once per sphere of its largest leaf: first the f32 filter over the
@@ -689,7 +669,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         { unsigned long long st_c; STAMP(st_c); st_prim += st_c - st_a; }
 #endif
         // next refill is due when enough lanes are idle and there is something to hand out, or nobody has a ray
-        const uint64_t hv = __ballot(have);
+        const uint64_t hv = __ballot(node != a_idle);
         if (hv == 0ull) break;
         if (n_cnt != 0u && 64 - (int)__popcll(hv) >= kRefillMin) break;
         }
@@ -837,15 +817,15 @@ DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, V3& o, V3
 }
 
 __global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, RenderDev rd, uint32_t n_init, uint32_t* __restrict__ next_work, uint32_t* __restrict__ out_count) {
-    __shared__ uint32_t s_scan[kShadeThreads / 64 + 1];
+    // the first fill of the pool needs no allocator: slot i takes work item i (the host passes n_init <= total_items), and the two
+    // counters get their values from one thread. (The atomics + barriers of block_alloc made this kernel latency-bound: 6.0 ms for
+    // 268 M paths at 41 % of the HBM write rate.)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t work = block_alloc(i < n_init, next_work, s_scan);
-    const bool got = work < rd.total_items;
-    const uint32_t dst = block_alloc(got, out_count, s_scan);
-    if (got) {
+    if (i == 0u) { *next_work = n_init; *out_count = n_init; }
+    if (i < n_init) {
         PathState s; V3 o, d; float tm;
-        start_item(rd, work, s, o, d, tm);
-        store_path(pool, dst, o, d, tm, s, rd.block_shift != 0u);
+        start_item(rd, i, s, o, d, tm);
+        store_path(pool, i, o, d, tm, s, rd.block_shift != 0u);
     }
 }
 
@@ -1259,7 +1239,7 @@ static hipError_t launch_extend_g(uint32_t n_groups, size_t lds_bytes, const Sce
 template <int MODE, uint32_t FEAT, bool COUNT>
 static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
-    const size_t lds_bytes = MODE == M_LDS ? (((size_t)sc.n_nodes + 2u) * rtd::NODE_STRIDE_LDS + (size_t)sc.n_spheres * 16u) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
+    const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
     // thread counts compiled for this mode: the small group always, the large one where a big LDS copy limits the groups per CU
     constexpr uint32_t kSmall = MODE == M_TOP ? 2u * kExtendThreads : kExtendThreads, kBig = 2u * kSmall;
     static thread_local size_t cached_lds = ~(size_t)0; static thread_local int nb_small = 0, nb_big = 0;

@@ -127,48 +127,57 @@ int rt_ctx_destroy(RtCtx* ctx) {
     return RT_OK;
 }
 
-// device layout of the threaded BVH (device_types.h: NodeDev) + the closing record, `stride` bytes per record
-static std::vector<unsigned char> device_nodes(const std::vector<rtd::Node>& nodes, uint32_t stride) {
-    std::vector<unsigned char> out((nodes.size() + 2) * (size_t)stride, 0);   // + closing record + one record of padding
+// ---- device layout of the threaded BVH (device_types.h: NodeDev and the text above it) -----------------------------------------
+// Every record carries BOTH of its links, as byte addresses: `hit` (where a walk goes when the box is passed) and `skip` (when it
+// is not). A lane of k_extend is then nothing but its address: one select per visit, no "am I walking" test. States that used to
+// be lane flags are records of their own that lead back to themselves: DONE (the walk ran off the end), IDLE (the lane holds no
+// ray), and one PARK TWIN per record with a leaf payload — the leaf's `hit` link. A lane that passes a leaf's box lands on the
+// twin and stays (its box cannot be passed: negative half extents) until the primitive pass reads the payload and the resume
+// address out of the twin and moves the lane on.
+//
+//   address space:  [0, top_bytes)            LDS copy of the top of the tree (scenes that do not fit LDS as a whole; else empty)
+//                   top_bytes + 32 * i         record i of the array (pre-order), i < n
+//                   special = top_bytes + 32n  DONE, then IDLE, then the twins in the order of their leaves
+//
+// The top = every record above a depth cut (depth = number of enclosing subtrees [i, skip_i) of the threaded array), the deepest cut
+// with at most `max_top` records: closed under "parent of", so a walk starts in it and re-enters it whenever a skip leads back up.
+struct DevNodes {
+    std::vector<unsigned char> main, top;   // main: records + DONE + IDLE + twins; top: the LDS copies (M_TOP)
+    uint32_t n = 0, n_top = 0, n_twins = 0;
+    uint32_t records() const { return n + 2u + n_twins; }
+};
+static void node_boxes(const std::vector<rtd::Node>& nodes, std::vector<rtd::NodeDev>& out) {
+    // boxes as centre c and half extent h, rounded outwards: [c-h, c+h] contains the (padded) host box plus the slack of the device's
+    // three roundings (tc, th, tc -+ th; ~3e-7 * (|c| + |o|) in space, |o| <= extent like scene_compile.cpp assumes)
     const float inf = std::numeric_limits<float>::infinity();
     double extent = 0.0;
     for (const rtd::Node& n : nodes) for (int a = 0; a < 3; ++a) {
         if (std::isfinite(n.mn[a])) extent = std::max(extent, (double)std::fabs(n.mn[a]));
         if (std::isfinite(n.mx[a])) extent = std::max(extent, (double)std::fabs(n.mx[a]));
     }
+    out.resize(nodes.size());
     for (size_t i = 0; i < nodes.size(); ++i) {
         const rtd::Node& n = nodes[i];
         float c[3], h[3];
         for (int a = 0; a < 3; ++a) {
-            if (!std::isfinite(n.mn[a]) || !std::isfinite(n.mx[a])) { c[a] = 0.f; h[a] = inf; continue; }
+            if (!std::isfinite(n.mn[a]) || !std::isfinite(n.mx[a])) { c[a] = 0.f; h[a] = inf; continue; }   // a record without a box is always passed
             c[a] = (float)(0.5 * ((double)n.mn[a] + (double)n.mx[a]));
-            // half extent that covers both planes from the ROUNDED centre, plus the slack of the device's three
-            // roundings (tc, th, tc -+ th; ~3e-7 * (|c| + |o|) in space, |o| <= extent like scene_compile.cpp assumes)
             double hd = std::max((double)n.mx[a] - (double)c[a], (double)c[a] - (double)n.mn[a]);
             hd = hd * (1.0 + 1e-6) + 5e-7 * (std::fabs((double)c[a]) + extent);
             float hf = (float)hd; if ((double)hf < hd) hf = std::nextafterf(hf, inf);
             h[a] = hf;
         }
-        const rtd::NodeDev d{c[0], c[1], h[0], h[1], c[2], h[2], n.skip * stride, n.leaf};
-        std::memcpy(out.data() + i * stride, &d, sizeof(d));
+        out[i] = rtd::NodeDev{c[0], c[1], h[0], h[1], c[2], h[2], 0u, 0u};
     }
-    const rtd::NodeDev end{0.f, 0.f, inf, inf, 0.f, inf, (uint32_t)nodes.size() * stride, rtd::LEAF_DONE};
-    std::memcpy(out.data() + nodes.size() * stride, &end, sizeof(end));
-    // the lane that "hits" the closing record parks with its offset one record further and keeps reading there: a second copy
-    std::memcpy(out.data() + (nodes.size() + 1) * stride, &end, sizeof(end));
-    return out;
 }
-// Layout for a scene that does not fit LDS as a whole (device_types.h: LEAF_DONE_TOP): the array in HBM plus a copy of the TOP of
-// the tree for LDS. The top = every record above a depth cut (depth = number of enclosing subtrees [i, skip_i) in the threaded
-// array), the deepest cut with at most `max_top` records — so it is closed under "parent of", a walk starts in it, and whenever a
-// `skip` leads back up it re-enters it. Returns false when there is nothing to gain (no cut fits) or the address space is too small.
-struct TopLayout { std::vector<unsigned char> hbm, top; uint32_t n_top = 0; };
-static bool device_nodes_top(const std::vector<rtd::Node>& nodes, uint32_t max_top, TopLayout& out) {
+static bool device_nodes(const std::vector<rtd::Node>& nodes, uint32_t max_top, DevNodes& out) {
     const size_t n = nodes.size();
-    if (n == 0 || max_top == 0) return false;
-    std::vector<uint32_t> depth(n), per_depth;
-    {
-        std::vector<uint32_t> ends;
+    out = DevNodes();
+    out.n = (uint32_t)n;
+    // ---- the top (optional) ----
+    std::vector<uint32_t> slot(n, 0xFFFFFFFFu);
+    if (max_top != 0u && n != 0) {
+        std::vector<uint32_t> depth(n), per_depth, ends;
         for (size_t i = 0; i < n; ++i) {
             while (!ends.empty() && ends.back() <= i) ends.pop_back();
             depth[i] = (uint32_t)ends.size();
@@ -176,34 +185,45 @@ static bool device_nodes_top(const std::vector<rtd::Node>& nodes, uint32_t max_t
             per_depth[depth[i]]++;
             if (nodes[i].skip > i + 1) ends.push_back(nodes[i].skip);
         }
+        uint32_t cut = 0; uint64_t total = 0;
+        while (cut < per_depth.size() && total + per_depth[cut] <= max_top) total += per_depth[cut++];
+        if (cut != 0 && total < n) { uint32_t k = 0; for (size_t i = 0; i < n; ++i) if (depth[i] < cut) slot[i] = k++; out.n_top = k; }
     }
-    uint32_t cut = 0; uint64_t total = 0;
-    while (cut < per_depth.size() && total + per_depth[cut] <= max_top) total += per_depth[cut++];
-    if (cut == 0 || total == n) return false;          // (a scene whose every record fits is LDS-resident as a whole already)
-    const uint32_t n_top = (uint32_t)total, top_bytes = n_top * 32u;
-    if ((uint64_t)top_bytes + (n + 2) * 32ull >= rtd::TOP_SPACE_BYTES) return false;
-    std::vector<uint32_t> slot(n, 0xFFFFFFFFu);
-    { uint32_t k = 0; for (size_t i = 0; i < n; ++i) if (depth[i] < cut) slot[i] = k++; }
-    auto U = [&](size_t i) -> uint32_t { return (i < n && slot[i] != 0xFFFFFFFFu) ? slot[i] * 32u : top_bytes + (uint32_t)i * 32u; };
-    const std::vector<unsigned char> plain = device_nodes(nodes, 32);     // boxes as (centre, half extent), padded: reuse
-    out.hbm.assign(plain.begin(), plain.end());
-    out.top.assign((size_t)n_top * 32, 0);
+    for (const rtd::Node& nd : nodes) if (nd.leaf != 0u) out.n_twins++;
+    const uint64_t top_bytes = (uint64_t)out.n_top * 32u, total_bytes = top_bytes + (uint64_t)out.records() * 32u;
+    if (total_bytes >= 0xFFFFFFF0ull) return false;                      // 32-bit byte addresses
+    const uint32_t special = (uint32_t)top_bytes + (uint32_t)n * 32u, done = special, idle = special + 32u, twin0 = special + 64u;
+    auto U = [&](size_t i) -> uint32_t { return i >= n ? done : (slot[i] != 0xFFFFFFFFu ? slot[i] * 32u : (uint32_t)top_bytes + (uint32_t)i * 32u); };
+    std::vector<rtd::NodeDev> box;
+    node_boxes(nodes, box);
+    out.main.assign((size_t)out.records() * 32, 0);
+    out.top.assign((size_t)top_bytes, 0);
+    auto put = [&](uint32_t offset_in_main, const rtd::NodeDev& d) { std::memcpy(out.main.data() + offset_in_main, &d, 32); };
+    auto self_loop = [&](uint32_t addr, uint32_t resume, uint32_t payload) {
+        rtd::NodeDev d{0.f, 0.f, -1.f, -1.f, 0.f, -1.f, addr, addr};     // h < 0: lo > hi on every axis, the box is never passed
+        std::memcpy(&d.cx, &resume, 4); std::memcpy(&d.cy, &payload, 4);
+        return d;
+    };
+    uint32_t k = 0;
     for (size_t i = 0; i < n; ++i) {
-        rtd::NodeDev d; std::memcpy(&d, plain.data() + i * 32, 32);
+        rtd::NodeDev d = box[i];
         d.skip_bytes = U(nodes[i].skip);
-        d.leaf = nodes[i].leaf != 0u ? nodes[i].leaf : U(i + 1);          // inner record: the hit link
-        std::memcpy(out.hbm.data() + i * 32, &d, 32);
+        if (nodes[i].leaf != 0u) {
+            const uint32_t twin = twin0 + 32u * k++;
+            d.leaf = twin;                                                // hit link -> its park twin
+            put(twin - (uint32_t)top_bytes, self_loop(twin, U(nodes[i].skip), nodes[i].leaf));   // resume = first record after the leaf
+        } else d.leaf = U(i + 1);                                         // hit link -> the next record in pre-order
+        put((uint32_t)i * 32u, d);
         if (slot[i] != 0xFFFFFFFFu) std::memcpy(out.top.data() + (size_t)slot[i] * 32, &d, 32);
     }
-    for (size_t k = n; k < n + 2; ++k) {                                   // closing record (twice, as in the plain layout)
-        rtd::NodeDev d; std::memcpy(&d, plain.data() + k * 32, 32);
-        d.skip_bytes = U(n); d.leaf = rtd::LEAF_DONE_TOP;
-        std::memcpy(out.hbm.data() + k * 32, &d, 32);
-    }
-    out.n_top = n_top;
+    put((uint32_t)n * 32u, self_loop(done, done, rtd::LEAF_DONE));
+    put((uint32_t)n * 32u + 32u, self_loop(idle, idle, rtd::LEAF_IDLE));
     return true;
 }
-static size_t lds_scene_bytes(const rtc::CompiledScene& cs) { return (cs.nodes.size() + 2) * (size_t)rtd::NODE_STRIDE_LDS + cs.spheres.size() * 16; }
+static size_t lds_scene_bytes(const rtc::CompiledScene& cs) {
+    size_t twins = 0; for (const rtd::Node& nd : cs.nodes) if (nd.leaf != 0u) ++twins;
+    return (cs.nodes.size() + 2 + twins) * 32 + cs.spheres.size() * 16;
+}
 
 int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
@@ -217,17 +237,15 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     int r = RT_OK;
     auto up = [&](auto& buf, const auto& vec) { if (r == RT_OK) r = upload(ctx, buf, vec); };
     const bool in_lds = lds_scene_bytes(cs) <= kLdsSceneBudget;
-    std::vector<unsigned char> dnodes;   // alive until the stream sync below
-    TopLayout tl;
-    // RT_TOP_NODES: records of the top of the tree kept in LDS for scenes that do not fit (0 = none; 2048 = 64 KB leaves two
-    // 1024-thread workgroups per CU, i.e. the full 32 waves)
-    uint32_t max_top = 2048u;
+    // RT_TOP_NODES: records of the top of the tree kept in LDS for scenes that do not fit as a whole (0 = none)
+    uint32_t max_top = 1024u;
     if (const char* e = getenv("RT_TOP_NODES")) max_top = (uint32_t)std::strtoul(e, nullptr, 10);
-    max_top = std::min<uint32_t>(max_top, (160u * 1024u) / 32u);
-    const bool top = !in_lds && device_nodes_top(cs.nodes, max_top, tl);
-    if (top) { dnodes.swap(tl.hbm); up(s->top_nodes, tl.top); }
-    else dnodes = device_nodes(cs.nodes, in_lds ? rtd::NODE_STRIDE_LDS : rtd::NODE_STRIDE_HBM);
-    up(s->nodes, dnodes); up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
+    max_top = std::min<uint32_t>(max_top, (128u * 1024u) / 32u);
+    DevNodes dn;   // alive until the stream sync below
+    if (!device_nodes(cs.nodes, in_lds ? 0u : max_top, dn)) { delete s; return set_err(ctx, RT_ERR_UNSUPPORTED, "scene: node array beyond 4 GB"); }
+    const bool top = dn.n_top != 0u;
+    if (top) up(s->top_nodes, dn.top);
+    up(s->nodes, dn.main); up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
     up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->media, cs.media);
     up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
     up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
@@ -235,7 +253,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     if (r != RT_OK) { rt_scene_destroy(ctx, s); return r; }
     rtk::SceneDev& d = s->dev;
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
-    d.top_nodes = top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = top ? tl.n_top : 0u;
+    d.top_nodes = top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = dn.n_top; d.n_records = dn.records();
     d.n_prim_kinds = (cs.sphere_meta.empty() ? 0u : 1u) + (cs.moving_meta.empty() ? 0u : 1u) + (cs.rect_meta.empty() ? 0u : 1u) +
                      (cs.tri_meta.empty() ? 0u : 1u) + (cs.media.empty() ? 0u : 1u);
     d.spheres = (const rtd::Float4*)s->spheres.p; d.sphere_meta = (const uint32_t*)s->sphere_meta.p; d.n_spheres = (uint32_t)cs.spheres.size();
@@ -385,11 +403,10 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) HIP_TRY(ctx, next_event(e0));
-    HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, P, c_next_work, c_count[0], ctx->stream));
+    const uint32_t n_init = (uint32_t)std::min<uint64_t>(P, total_items);
+    HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, n_init, c_next_work, c_count[0], ctx->stream));
     if (timing) { HIP_TRY(ctx, next_event(e1)); spans.push_back({e0, e1, 2}); }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count, c_count[0], 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    uint32_t live = ctx->h_count[0];   // upper bound of the pool's size from here on: it never grows
+    uint32_t live = n_init;   // upper bound of the pool's size from here on: it never grows
     int cur = 0;
     // Iterations are enqueued in batches without touching the host: the kernels read the pool size
     // from device memory and size-check themselves, so only termination needs a round trip.
@@ -496,34 +513,40 @@ int rt_scene_top_layout_check(const RtSceneDesc* desc, uint32_t max_top, uint64_
     rtc::CompiledScene cs;
     const int rc = rtc::compile_scene(*desc, cs);
     if (rc != RT_OK) return set_err(nullptr, rc, "scene: " + cs.error);
-    TopLayout tl;
+    DevNodes dn;
     if (out_n_top) *out_n_top = 0;
-    if (!device_nodes_top(cs.nodes, max_top, tl)) return RT_OK;        // no top: nothing to check
-    if (out_n_top) *out_n_top = tl.n_top;
+    if (!device_nodes(cs.nodes, max_top, dn)) return set_err(nullptr, RT_ERR_UNSUPPORTED, "node array beyond 4 GB");
+    if (out_n_top) *out_n_top = dn.n_top;
     const size_t n = cs.nodes.size();
-    const uint32_t top_bytes = tl.n_top * 32u;
+    const uint32_t top_bytes = dn.n_top * 32u, special = top_bytes + (uint32_t)n * 32u, done = special, idle = special + 32u, end = top_bytes + dn.records() * 32u;
     auto rec = [&](uint32_t addr) -> rtd::NodeDev {
         rtd::NodeDev d;
-        std::memcpy(&d, addr < top_bytes ? tl.top.data() + addr : tl.hbm.data() + (addr - top_bytes), 32);
+        std::memcpy(&d, addr < top_bytes ? dn.top.data() + addr : dn.main.data() + (addr - top_bytes), 32);
         return d;
     };
-    // unified address of every record, found by the walk that "hits" every box: it must enumerate the records in pre-order
+    auto word = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    auto parks = [&](uint32_t addr, uint32_t resume, uint32_t payload) {
+        if (addr < special || addr + 32u > end) return false;
+        const rtd::NodeDev t = rec(addr);
+        return t.skip_bytes == addr && t.leaf == addr && t.hx < 0.f && t.hy < 0.f && t.hz < 0.f && word(t.cx) == resume && word(t.cy) == payload;
+    };
+    // the walk that passes every box (and is moved on from every twin) must enumerate the records in pre-order
     std::vector<uint32_t> addr(n + 1);
     uint32_t a = 0;
     for (size_t i = 0; i < n; ++i) {
         addr[i] = a;
-        const rtd::NodeDev d = rec(a);
-        const rtd::NodeDev h = rec(top_bytes + (uint32_t)i * 32u);
-        if (std::memcmp(&d, &h, 32) != 0) return set_err(nullptr, RT_ERR_DEVICE, "top copy differs from the HBM record");
-        if (cs.nodes[i].leaf != 0u ? d.leaf != cs.nodes[i].leaf : (d.leaf >> 28) != 0u) return set_err(nullptr, RT_ERR_DEVICE, "leaf word");
-        a = (d.leaf >> 28) == 0u ? d.leaf : d.skip_bytes;
+        if (a >= special) return set_err(nullptr, RT_ERR_DEVICE, "walk left the records early");
+        const rtd::NodeDev d = rec(a), h = rec(top_bytes + (uint32_t)i * 32u);
+        if (std::memcmp(&d, &h, 32) != 0) return set_err(nullptr, RT_ERR_DEVICE, "top copy differs from the array's record");
+        if (cs.nodes[i].leaf != 0u) {
+            if (!parks(d.leaf, d.skip_bytes, cs.nodes[i].leaf)) return set_err(nullptr, RT_ERR_DEVICE, "park twin of record " + std::to_string(i));
+            a = d.skip_bytes;                                         // the twin's resume address
+        } else a = d.leaf;
     }
     addr[n] = a;
-    if (a != top_bytes + (uint32_t)n * 32u || rec(a).leaf != rtd::LEAF_DONE_TOP || rec(a).skip_bytes != a) return set_err(nullptr, RT_ERR_DEVICE, "closing record");
-    for (size_t i = 0; i < n; ++i) {
-        const uint32_t want = addr[std::min<size_t>(cs.nodes[i].skip, n)];
-        if (rec(addr[i]).skip_bytes != want) return set_err(nullptr, RT_ERR_DEVICE, "skip link of record " + std::to_string(i));
-    }
+    if (a != done || !parks(done, done, rtd::LEAF_DONE) || !parks(idle, idle, rtd::LEAF_IDLE)) return set_err(nullptr, RT_ERR_DEVICE, "closing records");
+    for (size_t i = 0; i < n; ++i)
+        if (rec(addr[i]).skip_bytes != addr[std::min<size_t>(cs.nodes[i].skip, n)]) return set_err(nullptr, RT_ERR_DEVICE, "skip link of record " + std::to_string(i));
     return RT_OK;
 }
 

@@ -17,7 +17,6 @@ VARIANTS = {
     "c128": ["RT_CHUNK=128"],
     "longwalk": ["RT_DEBUG_LONGWALK=1"],
     "c256": ["RT_CHUNK=256"],
-    "proot": ["RT_PARK_READS_ROOT=1"],
     "b16r16": ["RT_LEAF_BATCH=16", "RT_REFILL_MIN=16"],
     "c512": ["RT_CHUNK=512"],
     "c1024": ["RT_CHUNK=1024"],
@@ -39,7 +38,6 @@ VARIANTS = {
     "bs2": ["RT_BLOCK_SHIFT=2"],
     "bs3": ["RT_BLOCK_SHIFT=3"],
     "bs5": ["RT_BLOCK_SHIFT=5"],
-    "st48": ["RT_NODE_STRIDE_LDS=48"],
     "o6": ["RT_EXTEND_PER_CU_MAX=6"],
     "o5": ["RT_EXTEND_PER_CU_MAX=5"],
     "o4": ["RT_EXTEND_PER_CU_MAX=4"],
