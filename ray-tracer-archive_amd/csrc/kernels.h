@@ -36,14 +36,15 @@ struct SceneDev {
     const rtd::Light* lights; uint32_t n_lights;
 };
 
-// Path pool: structure of arrays, one 16-byte lane-contiguous record per array and slot.
-//   ray_o = (origin.xyz, time)         ray_d = (direction.xyz, -)         hit = (t, primitive id)
-//   s0 = (T.rgb, sample<<8|depth)   s1 = (acc.rgb, work item)   s2 = x|y<<16   s3 = rng counter (u64)
-// 84 bytes per path (+ 8 for the hit): T = throughput of the sample in flight, acc = sum over the finished
-// samples of the current work item. The radiance of the sample in flight needs no slot (kernels.hip PathState).
+// Path pool: structure of arrays, one lane-contiguous record per array and slot.
+//   ray_o = (origin.xyz, time)   ray_d = (direction.xyz, primitive the ray starts on)   hit = (t, primitive id), written by k_extend
+//   s0 = (T.rgb, work item)      s3 = (rng counter lo, hi, sample << 8 | depth)          s1 = (acc.rgb, -)  multi-sample items only
+// 60 bytes per path (+ 8 for the hit): T = throughput of the sample in flight, acc = sum over the finished samples of the current work
+// item. The radiance of the sample in flight needs no slot (kernels.hip PathState); the pixel is decoded from the work item.
+struct U3 { uint32_t x, y, z; };
 struct PoolDev {
     rtd::Float4* ray_o; rtd::Float4* ray_d; uint2* hit;
-    rtd::Float4* s0; uint4* s3; rtd::Float4* s1;   // s0 = (T.rgb, work item); s3 = (rng lo, hi, sample << 8 | depth, x | y << 16); s1 = acc (block_shift != 0 only)
+    rtd::Float4* s0; U3* s3; rtd::Float4* s1;
 };
 
 // Exact u32 division by a launch-invariant divisor: q = (t + ((n - t) >> s1)) >> s2 with t = umulhi(m, n)

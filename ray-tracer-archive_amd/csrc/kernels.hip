@@ -320,6 +320,57 @@ DEVI bool medium_hit(const SceneDev& sc, const rtd::Medium& m, V3 ow, V3 dw, flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// work items
+// ------------------------------------------------------------------------------------------------
+// A work item = (pixel, block of `block_len` consecutive samples). Items are numbered tile by tile over
+// this shard's tiles; tile_prefix[lt] = number of in-image pixels in local tiles < lt, so every item
+// maps to a pixel inside the image (edge tiles are clipped, not padded).
+struct WorkItem { uint32_t x, y, blk; };
+struct TileGeom { uint32_t x0, y0, w, h; };
+DEVI uint32_t fdivu(uint32_t n, const FastDiv& f) { const uint32_t t = __umulhi(f.m, n); return (t + ((n - t) >> f.s1)) >> f.s2; }
+DEVI TileGeom tile_geom(const RenderDev& rd, uint32_t lt) {
+    const uint32_t tile = rd.shard_index + lt * rd.shard_count;
+    const uint32_t ty = fdivu(tile, rd.div_tiles_x), tx = tile - ty * rd.tiles_x;
+    TileGeom g;
+    g.x0 = tx * rd.tile_size; g.y0 = ty * rd.tile_size;
+    g.w = min(rd.tile_size, rd.width - g.x0); g.h = min(rd.tile_size, rd.height - g.y0);
+    return g;
+}
+DEVI void tile_pixel(const RenderDev& rd, const TileGeom& g, uint32_t p, uint32_t& px, uint32_t& py) {
+    if (g.w == rd.tile_size && g.h == rd.tile_size) {
+        // full tile: 8x8 pixel squares, so a wave's 64 consecutive items cover one square
+        const uint32_t sq = p >> 6, in = p & 63u, sq_per_row = rd.tile_size >> 3;
+        const uint32_t row = fdivu(sq, rd.div_sq_row);
+        px = (sq - row * sq_per_row) * 8u + (in & 7u); py = row * 8u + (in >> 3);
+    } else { py = p / g.w; px = p - py * g.w; }
+}
+DEVI uint32_t find_tile(const RenderDev& rd, uint64_t key, uint32_t scale, uint32_t lo) {
+    // largest lt with tile_prefix[lt] * scale <= key. `lo` = key / (scale * ts^2) is exact when every tile before is
+    // full; clipped edge tiles move the answer up by at most tile_slack (host: clipped pixels / ts^2 + 1)
+    const uint32_t last = rd.n_local_tiles - 1u;
+    lo = min(lo, last);
+    uint32_t hi = min(last, lo + rd.tile_slack);
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if ((uint64_t)rd.tile_prefix[mid] * scale <= key) lo = mid; else hi = mid - 1u;
+    }
+    return lo;
+}
+DEVI WorkItem decode_work(const RenderDev& rd, uint32_t w) {
+    const uint32_t lt = find_tile(rd, w, rd.n_blocks, fdivu(w, rd.div_item_tile));
+    const TileGeom g = tile_geom(rd, lt);
+    const bool full = g.w == rd.tile_size && g.h == rd.tile_size;
+    const uint32_t valid = g.w * g.h;
+    const uint32_t r = w - rd.tile_prefix[lt] * rd.n_blocks;
+    WorkItem it;
+    it.blk = full ? fdivu(r, rd.div_ts2) : r / valid;
+    uint32_t px, py;
+    tile_pixel(rd, g, r - it.blk * valid, px, py);
+    it.x = g.x0 + px; it.y = g.y0 + py;
+    return it;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_extend — world.hit for the whole pool
 // ------------------------------------------------------------------------------------------------
 typedef float F2 __attribute__((ext_vector_type(2)));
@@ -495,9 +546,11 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     a = len2(d);
                     if (FEAT & F_XFORM) { ow = o; dw = d; }
                     if (FEAT & F_MEDIUM) {
-                        const uint4 q = pool.s3[slot]; const uint32_t sd = q.z, xy = q.w;
+                        // the free-path draws are keyed by the path's RNG base: pixel from the work item, sample from the state word
+                        const uint32_t sd = pool.s3[slot].z;
+                        const WorkItem it = decode_work(rd, __float_as_uint(pool.s0[slot].w));
                         seg = sd & 0xFFu;
-                        mkey = path_base(rd.seed, (uint64_t)(xy >> 16) * rd.width + (xy & 0xFFFFu), sd >> 8);
+                        mkey = path_base(rd.seed, (uint64_t)it.y * rd.width + it.x, sd >> 8);
                     }
                     tmax = kInf; node = 0u; hit_prim = rtd::HIT_NONE;   // address 0 = the root (the first record, or its copy in the top)
                 }
@@ -694,56 +747,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// work items, camera rays
+// camera rays
 // ------------------------------------------------------------------------------------------------
-// A work item = (pixel, block of `block_len` consecutive samples). Items are numbered tile by tile over
-// this shard's tiles; tile_prefix[lt] = number of in-image pixels in local tiles < lt, so every item
-// maps to a pixel inside the image (edge tiles are clipped, not padded).
-struct WorkItem { uint32_t x, y, blk; };
-struct TileGeom { uint32_t x0, y0, w, h; };
-DEVI uint32_t fdivu(uint32_t n, const FastDiv& f) { const uint32_t t = __umulhi(f.m, n); return (t + ((n - t) >> f.s1)) >> f.s2; }
-DEVI TileGeom tile_geom(const RenderDev& rd, uint32_t lt) {
-    const uint32_t tile = rd.shard_index + lt * rd.shard_count;
-    const uint32_t ty = fdivu(tile, rd.div_tiles_x), tx = tile - ty * rd.tiles_x;
-    TileGeom g;
-    g.x0 = tx * rd.tile_size; g.y0 = ty * rd.tile_size;
-    g.w = min(rd.tile_size, rd.width - g.x0); g.h = min(rd.tile_size, rd.height - g.y0);
-    return g;
-}
-DEVI void tile_pixel(const RenderDev& rd, const TileGeom& g, uint32_t p, uint32_t& px, uint32_t& py) {
-    if (g.w == rd.tile_size && g.h == rd.tile_size) {
-        // full tile: 8x8 pixel squares, so a wave's 64 consecutive items cover one square
-        const uint32_t sq = p >> 6, in = p & 63u, sq_per_row = rd.tile_size >> 3;
-        const uint32_t row = fdivu(sq, rd.div_sq_row);
-        px = (sq - row * sq_per_row) * 8u + (in & 7u); py = row * 8u + (in >> 3);
-    } else { py = p / g.w; px = p - py * g.w; }
-}
-DEVI uint32_t find_tile(const RenderDev& rd, uint64_t key, uint32_t scale, uint32_t lo) {
-    // largest lt with tile_prefix[lt] * scale <= key. `lo` = key / (scale * ts^2) is exact when every tile before is
-    // full; clipped edge tiles move the answer up by at most tile_slack (host: clipped pixels / ts^2 + 1)
-    const uint32_t last = rd.n_local_tiles - 1u;
-    lo = min(lo, last);
-    uint32_t hi = min(last, lo + rd.tile_slack);
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1u) >> 1;
-        if ((uint64_t)rd.tile_prefix[mid] * scale <= key) lo = mid; else hi = mid - 1u;
-    }
-    return lo;
-}
-DEVI WorkItem decode_work(const RenderDev& rd, uint32_t w) {
-    const uint32_t lt = find_tile(rd, w, rd.n_blocks, fdivu(w, rd.div_item_tile));
-    const TileGeom g = tile_geom(rd, lt);
-    const bool full = g.w == rd.tile_size && g.h == rd.tile_size;
-    const uint32_t valid = g.w * g.h;
-    const uint32_t r = w - rd.tile_prefix[lt] * rd.n_blocks;
-    WorkItem it;
-    it.blk = full ? fdivu(r, rd.div_ts2) : r / valid;
-    uint32_t px, py;
-    tile_pixel(rd, g, r - it.blk * valid, px, py);
-    it.x = g.x0 + px; it.y = g.y0 + py;
-    return it;
-}
-
 // One new sample: jitter (main.rs:752-753) then Camera::get_ray (camera.rs:60-70).
 DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t sample, Rng& g, V3& o, V3& d, float& tm) {
     const uint64_t pixel_index = (uint64_t)y * rd.width + x;
@@ -773,17 +778,18 @@ DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t s
 // that folds it into `acc`.
 struct PathState {
     V3 T, acc;
-    uint32_t work, sdepth, xy;   // sdepth = sample index << 8 | depth;  xy = x | y << 16
+    uint32_t work, sdepth;       // sdepth = sample index << 8 | depth
     uint32_t from;               // primitive id the ray starts on (hit-record id), 0 = none
     uint64_t rng;
 };
-// 64 bytes per path: ray_o, ray_d, s0 = (T, work item), s3 = (rng, sample << 8 | depth, x | y << 16); the running sum
+// 60 bytes per path: ray_o, ray_d, s0 = (T, work item), s3 = (rng, sample << 8 | depth) — the pixel is a function of the work item and is
+// decoded where it is needed (a new sample of a multi-sample item, the key of the medium draws), not carried; the running sum
 // `acc` (s1, +16 bytes) exists only when a work item is more than one sample (with_acc = block_shift != 0).
 DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const PathState& s, bool with_acc) {
     p.ray_o[i] = Float4{o.x, o.y, o.z, tm};
     p.ray_d[i] = Float4{d.x, d.y, d.z, __uint_as_float(s.from)};
     p.s0[i] = Float4{s.T.x, s.T.y, s.T.z, __uint_as_float(s.work)};
-    p.s3[i] = make_uint4((uint32_t)s.rng, (uint32_t)(s.rng >> 32), s.sdepth, s.xy);
+    p.s3[i] = U3{(uint32_t)s.rng, (uint32_t)(s.rng >> 32), s.sdepth};
     if (with_acc) p.s1[i] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
 }
 
@@ -813,7 +819,7 @@ DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, V3& o, V3
     const uint32_t sample = it.blk << rd.block_shift;
     new_camera_ray(rd, it.x, it.y, sample, g, o, d, tm);
     s.T = v3(1, 1, 1); s.acc = v3(0, 0, 0);
-    s.work = work; s.sdepth = sample << 8; s.xy = it.x | (it.y << 16); s.rng = g.s; s.from = 0u;
+    s.work = work; s.sdepth = sample << 8; s.rng = g.s; s.from = 0u;
 }
 
 __global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, RenderDev rd, uint32_t n_init, uint32_t* __restrict__ next_work, uint32_t* __restrict__ out_count) {
@@ -955,9 +961,9 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     bool want_work = false;
     if (alive) {
         const Float4 ro = in.ray_o[i], rdv = in.ray_d[i], s0 = in.s0[i];
-        const uint4 s3 = in.s3[i]; const uint2 hit = in.hit[i];
+        const U3 s3 = in.s3[i]; const uint2 hit = in.hit[i];
         o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
-        s.T = v3(s0.x, s0.y, s0.z); s.work = __float_as_uint(s0.w); s.sdepth = s3.z; s.xy = s3.w;
+        s.T = v3(s0.x, s0.y, s0.z); s.work = __float_as_uint(s0.w); s.sdepth = s3.z;
         if (with_acc) { const Float4 s1 = in.s1[i]; s.acc = v3(s1.x, s1.y, s1.z); }   // else 0: the item is this one sample
         V3 L = v3(0.f, 0.f, 0.f);          // radiance of this sample: set by the terminal event only
         s.rng = (uint64_t)s3.x | ((uint64_t)s3.y << 32);
@@ -1139,7 +1145,8 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
             s.acc = s.acc + L;
             sample++;
             if ((sample & ((1u << rd.block_shift) - 1u)) != 0u && sample < rd.spp) {
-                new_camera_ray(rd, s.xy & 0xFFFFu, s.xy >> 16, sample, g, o, d, tm);   // next sample of the same block
+                const WorkItem it = decode_work(rd, s.work);
+                new_camera_ray(rd, it.x, it.y, sample, g, o, d, tm);   // next sample of the same block
                 s.T = v3(1, 1, 1); depth = 0; s.from = 0u;
             } else {
                 rd.blocksum[s.work] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
@@ -1240,27 +1247,35 @@ template <int MODE, uint32_t FEAT, bool COUNT>
 static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
     const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
-    // thread counts compiled for this mode: the small group always, the large one where a big LDS copy limits the groups per CU
-    constexpr uint32_t kSmall = MODE == M_TOP ? 2u * kExtendThreads : kExtendThreads, kBig = 2u * kSmall;
-    static thread_local size_t cached_lds = ~(size_t)0; static thread_local int nb_small = 0, nb_big = 0;
+    // workgroup sizes compiled for this mode: 256 threads always; 512 and 1024 where an LDS copy limits the groups per CU (a
+    // 100 KB scene allows ONE group per CU: only a 1024-thread group then keeps 16 waves on it)
+    constexpr uint32_t T0 = kExtendThreads, T1 = MODE == M_HBM ? T0 : 2u * T0, T2 = MODE == M_HBM ? T0 : 4u * T0;
+    static thread_local size_t cached_lds = ~(size_t)0; static thread_local int nb[3] = {0, 0, 0}; static thread_local int pick = 0;
     if (cached_lds != lds_bytes) {
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_small, k_extend<MODE, FEAT, COUNT, kSmall>, (int)kSmall, lds_bytes);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[0], k_extend<MODE, FEAT, COUNT, T0>, (int)T0, lds_bytes);
         if (e != hipSuccess) return e;
-        nb_big = 0;
+        nb[1] = nb[2] = 0;
         if (MODE != M_HBM) {
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_big, k_extend<MODE, FEAT, COUNT, (MODE != M_HBM ? kBig : kSmall)>, (int)kBig, lds_bytes);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[1], k_extend<MODE, FEAT, COUNT, T1>, (int)T1, lds_bytes);
+            if (e != hipSuccess) return e;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[2], k_extend<MODE, FEAT, COUNT, T2>, (int)T2, lds_bytes);
             if (e != hipSuccess) return e;
         }
-        if (nb_small < 1) nb_small = 1;
 #ifdef RT_EXTEND_PER_CU_MAX
-        nb_small = std::min(nb_small, RT_EXTEND_PER_CU_MAX); nb_big = std::min(nb_big, RT_EXTEND_PER_CU_MAX / 2);   // tuning builds only
+        nb[0] = std::min(nb[0], RT_EXTEND_PER_CU_MAX); nb[1] = std::min(nb[1], RT_EXTEND_PER_CU_MAX / 2); nb[2] = std::min(nb[2], RT_EXTEND_PER_CU_MAX / 4);   // tuning builds only
 #endif
+        // most resident waves wins; ties go to the smaller group (its waves leave the staging barrier sooner)
+        pick = 0;
+        if (2 * nb[1] > nb[0]) pick = 1;
+        if (4 * nb[2] > std::max(nb[0], 2 * nb[1])) pick = 2;
+        if (nb[pick] < 1) { if (lds_bytes > 160u * 1024u) return hipErrorInvalidValue; nb[pick] = 1; }
         cached_lds = lds_bytes;
     }
-    if (cfg.extend_geometry) { cfg.extend_geometry[0] = (uint32_t)nb_small; cfg.extend_geometry[1] = (uint32_t)nb_big; }
-    if (MODE != M_HBM && 2 * nb_big > nb_small)
-        return launch_extend_g<MODE, FEAT, COUNT, (MODE != M_HBM ? kBig : kSmall)>(cfg.n_cu * (uint32_t)nb_big, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
-    return launch_extend_g<MODE, FEAT, COUNT, kSmall>(cfg.n_cu * (uint32_t)nb_small, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
+    if (cfg.extend_geometry) { cfg.extend_geometry[0] = (uint32_t)(pick == 0 ? T0 : pick == 1 ? T1 : T2); cfg.extend_geometry[1] = (uint32_t)nb[pick]; }
+    const uint32_t groups = cfg.n_cu * (uint32_t)nb[pick];
+    if (MODE != M_HBM && pick == 2) return launch_extend_g<MODE, FEAT, COUNT, T2>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
+    if (MODE != M_HBM && pick == 1) return launch_extend_g<MODE, FEAT, COUNT, T1>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
+    return launch_extend_g<MODE, FEAT, COUNT, T0>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
 }
 template <int MODE, uint32_t FEAT>
 static hipError_t launch_extend_t(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,

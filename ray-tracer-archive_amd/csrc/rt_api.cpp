@@ -23,7 +23,7 @@ namespace rti { thread_local std::string g_last_error; }
 namespace {
 
 constexpr uint64_t kMaxItems = (1ull << 32) - (1ull << 28);   // work items of one render (u32 index, with head room for the allocator's overshoot)
-constexpr size_t kLdsSceneBudget = 64 * 1024;   // nodes + sphere records staged per workgroup
+constexpr size_t kLdsSceneBudget = 144 * 1024;  // records + sphere data staged per workgroup (one 1024-thread group per CU then; 160 KB of LDS)
 
 template <class T> int upload(RtCtx* ctx, DevBuf& b, const std::vector<T>& v) {
     HIP_TRY(ctx, b.ensure(v.size() * sizeof(T)));
@@ -350,7 +350,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
 
     // Pool: as many paths in flight as there are work items, up to 2^28 (45 GB for the two pools) and to what the
     // device has free. Launches then carry hundreds of millions of rays: few launches, short tails.
-    const size_t rec[6] = {16, 16, 8, 16, 16, block_shift ? (size_t)16 : (size_t)0};   // ray_o ray_d hit s0 s3 [s1 = acc]
+    const size_t rec[6] = {16, 16, 8, 16, 12, block_shift ? (size_t)16 : (size_t)0};   // ray_o ray_d hit s0 s3 [s1 = acc]
     size_t slot_bytes = 0; for (int a = 0; a < 6; ++a) slot_bytes += 2 * rec[a];
     uint32_t P = prm->pool_slots ? prm->pool_slots : (1u << 28);
     P = (uint32_t)std::min<uint64_t>(P, total_items);
@@ -368,7 +368,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     for (int k = 0; k < 2; ++k) {
         for (int a = 0; a < 6; ++a) if (rec[a]) HIP_TRY(ctx, ctx->pool[k][a].ensure((size_t)P * rec[a]));
         pd[k].ray_o = (rtd::Float4*)ctx->pool[k][0].p; pd[k].ray_d = (rtd::Float4*)ctx->pool[k][1].p; pd[k].hit = (uint2*)ctx->pool[k][2].p;
-        pd[k].s0 = (rtd::Float4*)ctx->pool[k][3].p; pd[k].s3 = (uint4*)ctx->pool[k][4].p; pd[k].s1 = rec[5] ? (rtd::Float4*)ctx->pool[k][5].p : nullptr;
+        pd[k].s0 = (rtd::Float4*)ctx->pool[k][3].p; pd[k].s3 = (rtk::U3*)ctx->pool[k][4].p; pd[k].s1 = rec[5] ? (rtd::Float4*)ctx->pool[k][5].p : nullptr;
     }
     HIP_TRY(ctx, ctx->blocksum.ensure((size_t)total_items * 16));
     rd.blocksum = (rtd::Float4*)ctx->blocksum.p;
@@ -408,25 +408,40 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     if (timing) { HIP_TRY(ctx, next_event(e1)); spans.push_back({e0, e1, 2}); }
     uint32_t live = n_init;   // upper bound of the pool's size from here on: it never grows
     int cur = 0;
-    // Iterations are enqueued in batches without touching the host: the kernels read the pool size
-    // from device memory and size-check themselves, so only termination needs a round trip.
-    uint32_t batch = 4, launched = 0;
+    // The host never waits for an iteration it has just enqueued: the kernels read the pool size from device memory and size-check
+    // themselves, so the host only needs (a) an UPPER BOUND of the pool size to size k_shade's grid and (b) to learn that it has
+    // reached 0. After every iteration the size is copied to a pinned ring slot behind an event; before enqueuing the next
+    // iteration the host takes whatever copies have landed (the size never grows, so an older value is a valid bound) and blocks
+    // only when it is kAhead iterations ahead. (Batches of 4, 8, 16, 32 iterations with a blocking read in between sized eight
+    // launches of k_shade by the 268 M paths of the start while 5 M were alive — 0.6 ms each for empty workgroups.)
+    constexpr uint32_t kAhead = 3, kRing = 8;
+    struct Pending { hipEvent_t ev; uint32_t ring; };
+    std::vector<Pending> pending;      // oldest first
+    size_t pending_head = 0;
+    auto take = [&](const Pending& pd_) { live = std::min(live, ctx->h_count[pd_.ring]); };
+    uint32_t launched = 0;
     while (live > 0) {
-        for (uint32_t k = 0; k < batch; ++k) {
-            hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
-            if (timing) HIP_TRY(ctx, next_event(ea));
-            HIP_TRY(ctx, rtk::launch_extend(cfg, scene->dev, pd[cur], rd, c_count[cur], c_head, c_count[1 - cur], c64, counting, ctx->stream));
-            if (timing) HIP_TRY(ctx, next_event(eb));
-            HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, c_count[cur], c_count[1 - cur], c_next_work, c_head, c64, counting,
-                                           ctx->stream));
-            if (timing) { HIP_TRY(ctx, next_event(ec)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); }
-            cur = 1 - cur;
-            ++launched;
+        while (pending_head < pending.size() && hipEventQuery(pending[pending_head].ev) == hipSuccess) take(pending[pending_head++]);
+        if (live == 0) break;
+        if (pending.size() - pending_head >= kAhead) {
+            HIP_TRY(ctx, hipEventSynchronize(pending[pending_head].ev));
+            take(pending[pending_head++]);
+            if (live == 0) break;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count, c_count[cur], 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        live = ctx->h_count[0];
-        if (batch < 32) batch *= 2;
+        hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
+        if (timing) HIP_TRY(ctx, next_event(ea));
+        HIP_TRY(ctx, rtk::launch_extend(cfg, scene->dev, pd[cur], rd, c_count[cur], c_head, c_count[1 - cur], c64, counting, ctx->stream));
+        if (timing) HIP_TRY(ctx, next_event(eb));
+        HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, c_count[cur], c_count[1 - cur], c_next_work, c_head, c64, counting,
+                                       ctx->stream));
+        if (timing) { HIP_TRY(ctx, next_event(ec)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); }
+        cur = 1 - cur;
+        const uint32_t ring = launched % kRing;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count + ring, c_count[cur], 4, hipMemcpyDeviceToHost, ctx->stream));
+        hipEvent_t ev = nullptr;
+        HIP_TRY(ctx, next_event(ev));
+        pending.push_back({ev, ring});
+        ++launched;
         if (launched > 100000000u) return set_err(ctx, RT_ERR_DEVICE, "render loop did not terminate");
     }
     hipEvent_t r0 = nullptr, r1 = nullptr;
@@ -449,7 +464,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
             for (int k = 0; k < RT_N_PRIM_TYPES; ++k) stats->prim_tests[k] = ctx->h_counters[rtk::CTR_PRIM_TESTS + k];
         }
         for (int k = 0; k < 5; ++k) stats->debug[k] = ctx->h_counters[rtk::CTR_DEBUG + k];
-        stats->debug[6] = extend_geometry[0]; stats->debug[7] = extend_geometry[1];   // resident k_extend groups per CU (256 / 512 threads)
+        stats->debug[6] = extend_geometry[0]; stats->debug[7] = extend_geometry[1];   // k_extend: threads per workgroup, resident workgroups per CU
         stats->iterations = (uint32_t)ctx->h_counters[rtk::CTR_ITERATIONS]; stats->extend_launches = launched; stats->shade_launches = launched; stats->pool_slots = P;
         stats->n_devices = 1u; stats->lds_top_nodes = scene->dev.n_top;
         stats->scene_nodes = scene->n_nodes; stats->scene_prims = scene->n_prims; stats->scene_bytes = scene->bytes; stats->bvh_in_lds = scene->in_lds ? 1u : 0u;
