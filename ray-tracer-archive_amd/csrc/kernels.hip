@@ -215,6 +215,42 @@ DEVI bool sphere_roots(V3 o, V3 d, float a, V3 c, float r, float tmin, float tma
     t = root;
     return true;
 }
+// The same test in robust f32 — the usual case — with its own error estimate: 0 = miss, 1 = hit (t set), 2 = not decided here
+// (the f64 path above decides). The discriminant comes from the offset l of the centre from the ray's line (l = oc - (hb/a) d,
+// |l|^2 carries an absolute error ~6 eps sqrt(|l|^2 |oc|^2), not the eps |oc|^2 of hb^2 - a c), so for a sphere that is small
+// against its distance the half chord sqrt(delta / a) is good to ~1e-7; the estimate sends the rest to f64: spheres as large as
+// their distance (the r = 1000 ground: always), grazing hits (delta within its error), origins close to the surface (the c/q root).
+#ifndef RT_SPHERE_TOL
+#define RT_SPHERE_TOL 1e-5f     // accepted error of a root, in units of the ray parameter
+#endif
+DEVI int sphere_fast(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax, float& t) {
+    constexpr float kEps = 5.9604645e-8f;                                   // 2^-24
+    const V3 oc = o - c;
+    const float hb = fmaf(oc.z, d.z, fmaf(oc.y, d.y, oc.x * d.x)), l2 = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, oc.x * oc.x)), r2 = r * r;
+    const float inva = fast_rcp(a), tq = hb * inva;
+    const V3 l = v3(fmaf(-tq, d.x, oc.x), fmaf(-tq, d.y, oc.y), fmaf(-tq, d.z, oc.z));
+    const float lp2 = fmaf(l.z, l.z, fmaf(l.y, l.y, l.x * l.x));
+    const float delta = r2 - lp2;                                           // discriminant / a
+    if (delta < -4.f * kEps * (lp2 + l2)) return 0;                         // the line passes outside, beyond any rounding
+    // error of delta ~ 6 eps sqrt(lp2 l2) (+ 2 eps lp2); half chord h = sqrt(delta / a): dh = E / (2 sqrt(a delta)) < tol
+    //   <=>  E^2 < 4 tol^2 a delta,  E^2 <= 54 eps^2 lp2 l2 with the small term folded in
+    constexpr float k1 = 54.f * kEps * kEps / (4.f * RT_SPHERE_TOL * RT_SPHERE_TOL);
+    const float ad = a * delta;
+    if (!(k1 * lp2 * l2 < ad)) return 2;                                    // also delta <= 0 within its error, NaN
+    const float sq = __builtin_amdgcn_sqrtf(ad);
+    const float q = hb > 0.f ? -(hb + sq) : (sq - hb);                      // -half_b -/+ sqrt(det) without cancellation
+    const float cc = l2 - r2;                                               // the other root is c / q: c good to eps (l2 + r2)
+    if (!(kEps * (l2 + r2) < RT_SPHERE_TOL * fabsf(q))) return 2;
+    const float tqq = q * inva, tc = cc * fast_rcp(q);
+    const float t_near = hb > 0.f ? tqq : tc, t_far = hb > 0.f ? tc : tqq;
+    float root = t_near;
+    if (root < tmin || tmax < root) {
+        root = t_far;
+        if (root < tmin || tmax < root) return 0;
+    }
+    t = root;
+    return 1;
+}
 DEVI bool sphere_hit(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax, float& t) {
     if (sphere_certain_miss(o, d, a, c, r)) return false;
     return sphere_roots(o, d, a, c, r, tmin, tmax, t);
@@ -659,6 +695,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             const uint32_t type = pend >> 28, cnt = (pend >> 24) & 15u, first = pend & rtd::LEAF_MAX_FIRST;
             node = resume;                                        // the record after the leaf, once its primitives are tested
             if (type == rtd::LT_SPHERE) {
+#ifdef RT_SPHERE_F64_ONLY
                 // two phases, so that the f64 refinement (several times the cost of the filter) runs once per SURVIVOR
                 // of the wave's slowest lane, not once per sphere of its largest leaf: first the f32 filter over the
                 // leaf, survivors as a bit mask (count <= 15); then the survivors in leaf order — the order in which
@@ -670,6 +707,21 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     const uint32_t id = (rtd::LT_SPHERE << 28) | (first + k);
                     if (id == from || !sphere_certain_miss(o, d, a, v3(s.x, s.y, s.z), s.w)) surv |= 1u << k;
                 }
+#else
+                // first the robust f32 test over the leaf in leaf order (the order in which HittableList::hit shrinks t_max); the few
+                // spheres it cannot decide (bit mask, count <= 15) get the f64 evaluation afterwards, together for the whole wave.
+                // A sphere decided later only ever lowers t_max further, so the closest hit is the same.
+                uint32_t surv = 0u;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4 s = spheres[first + k];
+                    if (COUNT) c_prims[0]++;
+                    const uint32_t id = (rtd::LT_SPHERE << 28) | (first + k);
+                    float t;
+                    const int r = id == from ? 2 : sphere_fast(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t);
+                    if (r == 1) { tmax = t; hit_prim = id; }
+                    surv |= (r == 2 ? 1u : 0u) << k;
+                }
+#endif
                 while (surv != 0u) {
                     const uint32_t k = (uint32_t)__builtin_ctz(surv);
                     surv &= surv - 1u;

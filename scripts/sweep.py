@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {
     "base": [],
+    "f64only": ["RT_SPHERE_F64_ONLY=1"],
+    "tol6": ["RT_SPHERE_TOL=1e-6f"],
+    "tol4": ["RT_SPHERE_TOL=1e-4f"],
     "libm": ["RT_LIBM_SINCOS=1"],
     "stamps": ["RT_STAMPS=1"],
     "r1": ["RT_REFILL_MIN=1"],
