@@ -94,6 +94,7 @@ pub const RT_NAN_REFERENCE: u32 = 1;     // main.rs:146-155: the pixel SUM is sc
 pub const RT_FLAG_COUNTERS: u32 = 1;
 pub const RT_FLAG_TIMING: u32 = 2;
 pub const RT_FLAG_SAMPLE_BLOCKS: u32 = 4;
+pub const RT_FLAG_FUSED: u32 = 8;         // diagnostic: the whole render by the fused per-path (tail) kernel
 #[repr(C)] #[derive(Clone, Copy, Default, Debug)]
 pub struct RtParams {
     pub width: u32, pub height: u32, pub samples_per_pixel: u32, pub max_depth: u32, pub seed: u64,
@@ -107,7 +108,7 @@ pub struct RtStats {
     pub samples: u64, pub segments: u64, pub node_tests: u64, pub prim_tests: [u64; RT_N_PRIM_TYPES],
     pub iterations: u32, pub extend_launches: u32, pub shade_launches: u32, pub pool_slots: u32,
     pub scene_nodes: u64, pub scene_prims: u64, pub scene_bytes: u64, pub bvh_in_lds: u32, pub _pad: u32, pub debug: [u64; 8],
-    pub gather_ms: f64, pub n_devices: u32, pub lds_top_nodes: u32,
+    pub gather_ms: f64, pub n_devices: u32, pub lds_top_nodes: u32, pub drain_ms: f64, pub drain_paths: u32, pub _pad2: u32,
 }
 
 #[repr(C)] #[derive(Clone, Copy, Default, Debug)]

@@ -168,8 +168,10 @@ typedef enum RtNanPolicy {
 enum {
     RT_FLAG_COUNTERS = 1u,  /* count AABB tests and primitive tests on the device (slower) */
     RT_FLAG_TIMING = 2u,    /* bracket every kernel launch with HIP events (RtStats *_ms) */
-    RT_FLAG_SAMPLE_BLOCKS = 4u  /* work items of 16 consecutive samples of a pixel, as for images of 2^32 - 2^28 samples and more
+    RT_FLAG_SAMPLE_BLOCKS = 4u, /* work items of 16 consecutive samples of a pixel, as for images of 2^32 - 2^28 samples and more
                                    (default below that: one sample per item). Per-pixel sums then differ in the last bits. */
+    RT_FLAG_FUSED = 8u          /* diagnostic: the whole render by the fused per-path kernel that normally carries only the tail (one
+                                   lane per path from first ray to last bounce). Bit-identical frame, slower. */
 };
 
 typedef struct RtParams {
@@ -212,6 +214,9 @@ typedef struct RtStats {
     double gather_ms;         /* multi-GPU: RCCL gather + untile on the root device (HIP events on the root's stream) */
     uint32_t n_devices;       /* GPUs that took part (1 for rt_render / rt_render_device) */
     uint32_t lds_top_nodes;   /* node records of the top of the tree staged in LDS when the whole scene does not fit (0 otherwise) */
+    double drain_ms;          /* duration of the fused kernel that carries the last paths to their end (RT_FLAG_TIMING) */
+    uint32_t drain_paths;     /* upper bound of the paths handed to it (0: the wavefront loop ran to the end) */
+    uint32_t _pad2;
 } RtStats;
 
 typedef struct RtCtx RtCtx;      /* one per (process, device, stream); not re-entrant (one render at a time per context; distinct

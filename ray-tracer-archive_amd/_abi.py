@@ -13,7 +13,7 @@ RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT, RT_MAT
 RT_BG_CONSTANT, RT_BG_SKY_GRADIENT = 0, 1
 RT_BVH_REFERENCE, RT_BVH_SAH = 0, 1
 RT_NAN_PER_SAMPLE, RT_NAN_REFERENCE = 0, 1
-RT_FLAG_COUNTERS, RT_FLAG_TIMING, RT_FLAG_SAMPLE_BLOCKS = 1, 2, 4
+RT_FLAG_COUNTERS, RT_FLAG_TIMING, RT_FLAG_SAMPLE_BLOCKS, RT_FLAG_FUSED = 1, 2, 4, 8
 RT_OUT_RGB_SUM_F32, RT_OUT_RGB8 = 0, 1
 RT_COMM_ID_BYTES = 128
 
@@ -73,7 +73,8 @@ class RtStats(C.Structure):
                 ("samples", C.c_uint64), ("segments", C.c_uint64), ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64 * RT_N_PRIM_TYPES),
                 ("iterations", C.c_uint32), ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("pool_slots", C.c_uint32),
                 ("scene_nodes", C.c_uint64), ("scene_prims", C.c_uint64), ("scene_bytes", C.c_uint64), ("bvh_in_lds", C.c_uint32), ("_pad", C.c_uint32), ("debug", C.c_uint64 * 8),
-                ("gather_ms", C.c_double), ("n_devices", C.c_uint32), ("lds_top_nodes", C.c_uint32)]
+                ("gather_ms", C.c_double), ("n_devices", C.c_uint32), ("lds_top_nodes", C.c_uint32),
+                ("drain_ms", C.c_double), ("drain_paths", C.c_uint32), ("_pad2", C.c_uint32)]
 
     def as_dict(self):
         d = {}

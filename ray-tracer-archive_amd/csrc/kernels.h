@@ -91,6 +91,9 @@ hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_
 // the count the following k_shade appends to, k_shade zeroes the queue head of the next k_extend.
 hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                          uint32_t* head, uint32_t* count_out_to_zero, unsigned long long* counters, bool count, hipStream_t stream);
+// The rest of a render in one launch: every path of `pool` (at most max_count) is carried to its end by one lane (kernels.hip DRAIN).
+hipError_t launch_drain(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, uint32_t max_count, const uint32_t* count_ptr,
+                        uint32_t* head, uint32_t* count_out_to_zero, uint32_t* next_work, unsigned long long* counters, bool count, hipStream_t stream);
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
                         const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, uint32_t* head_to_zero, unsigned long long* counters,
                         bool count, hipStream_t stream);

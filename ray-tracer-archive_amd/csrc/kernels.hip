@@ -461,11 +461,34 @@ constexpr int kLeafBatch = RT_LEAF_BATCH;
 // Infinity Cache). M_TOP: the scene does not fit, so the TOP of the tree (rt_api.cpp: every record above a depth cut) is staged in
 // LDS and the rest stays in HBM; addresses below top_bytes are LDS slots, the others HBM offsets + top_bytes, and since every
 // record carries its links in that one space a walk moves between the two memories without knowing it.
+//
+// DRAIN: the same kernel as the whole path loop for the TAIL of a render (and, with RT_FLAG_FUSED, for all of it): lane i takes path i
+// of the pool and keeps it — a lane on DONE is shaded in place (shade_segment, the code k_shade runs), gets its next ray and walks
+// again; a finished path draws new work while there is any. No queue, no pool traffic, no launch per bounce: once only a few
+// million paths are alive the wavefront iterations are launch- and latency-bound (41 of 53 iterations moved 1 % of the segments
+// in 7 % of the time), and one kernel that carries each path to its end replaces them. Same functions, same order per path:
+// the frame is bit-identical wherever the hand-over happens.
 enum : int { M_HBM = 0, M_LDS = 1, M_TOP = 2 };
-template <int MODE, uint32_t FEAT, bool COUNT, uint32_t TPB>
+struct PathState;
+template <uint32_t FEAT> DEVI bool shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& d, float& tm, PathState& s, Rng& g, uint32_t& depth, uint2 hit, V3& L,
+                                                 unsigned long long& c_light_rect, unsigned long long& c_light_sphere);
+DEVI bool finish_sample(const RenderDev& rd, PathState& s, Rng& g, uint32_t& sample, uint32_t& depth, V3 L, V3& o, V3& d, float& tm);
+DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, V3& o, V3& d, float& tm);
+// L, the radiance of the sample in flight, is not part of the state: `emitted` is non-zero only for
+// DiffuseLight, which never scatters (material.rs:12-14,184-190), and the background is returned on a miss
+// (main.rs:74-76) — so radiance is only ever added by the event that ENDS the path, in the same shading step
+// that folds it into `acc`.
+struct PathState {
+    V3 T, acc;
+    uint32_t work, sdepth;       // sdepth = sample index << 8 | depth
+    uint32_t from;               // primitive id the ray starts on (hit-record id), 0 = none
+    uint64_t rng;
+};
+constexpr int kShadeBatch = 16;   // DRAIN: lanes on DONE that trigger a shading pass
+template <int MODE, uint32_t FEAT, bool COUNT, uint32_t TPB, bool DRAIN>
 __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
                                                  uint32_t* __restrict__ head, uint32_t* __restrict__ count_out_to_zero,
-                                                 unsigned long long* __restrict__ counters, RenderDev rd) {
+                                                 unsigned long long* __restrict__ counters, RenderDev rd, uint32_t* __restrict__ next_work) {
     extern __shared__ float4 lds[];
     constexpr bool LDS = MODE == M_LDS, TOP = MODE == M_TOP;
     if (blockIdx.x == 0 && threadIdx.x == 0) *count_out_to_zero = 0u;   // the next k_shade appends to it
@@ -479,7 +502,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     const uint32_t head0 = n_waves * chunk;         // the dynamic part of the queue starts behind the static chunks
     // Short queue (the long tail of a render, hundreds of launches with a few thousand rays): a workgroup whose
     // waves own no static chunk has no dynamic chunk to fetch either — leave before staging the scene.
-    if (blockIdx.x * (blockDim.x >> 6) * chunk >= count && head0 >= count) return;
+    if (!DRAIN && blockIdx.x * (blockDim.x >> 6) * chunk >= count && head0 >= count) return;
+    if (DRAIN && blockIdx.x * blockDim.x >= count) return;                  // lane i carries path i
     const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
     const float4* spheres = reinterpret_cast<const float4*>(sc.spheres);
     const uint32_t top_bytes = TOP ? sc.n_top * 32u : 0u;
@@ -556,6 +580,35 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         if constexpr (LDS) { const U2V v = *reinterpret_cast<lds_u2>(off); return make_uint2(v.x, v.y); }
         else return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(nodes) + (off - top_bytes));
     };
+    // ---- DRAIN: the lane's path, for its whole life ----
+    PathState ps{}; Rng g; g.s = 0; uint32_t depth = 0, sample = 0;
+    unsigned long long c_segments = 0, c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
+    const bool with_acc = rd.block_shift != 0u;
+    // a ray the lane has just been given (by the pool or by shading): per-ray constants, walk from the root
+    auto begin_walk = [&]() {
+        set_slab_ray(o, d, sr);
+        a = len2(d);
+        if (FEAT & F_XFORM) { ow = o; dw = d; }
+        if (FEAT & F_MEDIUM) {
+            const WorkItem it = decode_work(rd, ps.work);
+            seg = depth;
+            mkey = path_base(rd.seed, (uint64_t)it.y * rd.width + it.x, sample);
+        }
+        from = ps.from; tmax = kInf; hit_prim = rtd::HIT_NONE; node = 0u;
+    };
+    if (DRAIN) {
+        const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < count) {
+            const Float4 ro = pool.ray_o[i], rdv = pool.ray_d[i], s0 = pool.s0[i];
+            const U3 s3 = pool.s3[i];
+            o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
+            ps.T = v3(s0.x, s0.y, s0.z); ps.work = __float_as_uint(s0.w); ps.sdepth = s3.z; ps.from = __float_as_uint(rdv.w);
+            if (with_acc) { const Float4 s1 = pool.s1[i]; ps.acc = v3(s1.x, s1.y, s1.z); }
+            g.s = (uint64_t)s3.x | ((uint64_t)s3.y << 32);
+            depth = ps.sdepth & 0xFFu; sample = ps.sdepth >> 8;
+            begin_walk();
+        }
+    }
     // One outer iteration = one refill. The ray records of the next 64 queue slots are loaded into No/Nd at
     // the END of a refill (one unconditional definition per iteration, so hipcc keeps the loads in flight) and
     // handed out at the NEXT refill by __shfl (ds_bpermute): the wave no longer parks on HBM latency with
@@ -565,7 +618,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     for (;;) {
         STAMP(st_a);
         // ---- refill: idle lanes take prefetched rays (ballot + prefix rank) ----
-        {
+        if constexpr (!DRAIN) {
             const bool is_idle = node == a_idle;
             const uint64_t idle = __ballot(is_idle);
             const uint32_t take = min((uint32_t)__popcll(idle), n_cnt);
@@ -610,7 +663,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             const uint32_t idx = n_cnt != 0u ? w_next + min(lane, n_cnt - 1u) : 0u;
             No = pool.ray_o[idx]; Nd = pool.ray_d[idx];
         }
-        if (__ballot(node != a_idle) == 0ull && n_cnt == 0u) break;       // queue empty, nothing in flight
+        if (__ballot(node != a_idle) == 0ull && (DRAIN || n_cnt == 0u)) break;       // queue empty, nothing in flight
 #ifdef RT_STAMPS
         STAMP(st_b); st_refill += st_b - st_a;
 #endif
@@ -640,7 +693,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             node = tnear <= tfar ? __float_as_uint(n1.w) : __float_as_uint(n1.z);             // hit : skip
         }
         // ---- events, outside the steps: lanes on a self-loop record ----
-        if (node == a_done) {                                                // walked off the end: world.hit is done
+        if (!DRAIN && node == a_done) {                                      // walked off the end: world.hit is done
             pool.hit[slot] = make_uint2(__float_as_uint(tmax), hit_prim);
 #ifdef RT_DEBUG_LONGWALK
             if (COUNT && dbg_steps > 100000u) {
@@ -773,11 +826,60 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         { unsigned long long st_c; STAMP(st_c); st_prim += st_c - st_a; }
 #endif
+        if constexpr (DRAIN) {
+            // ---- shading pass: when enough lanes have finished their walk, or nobody can do anything else ----
+            const uint64_t dm = __ballot(node == a_done);
+            if (dm != 0ull && ((int)__popcll(dm) >= kShadeBatch || __ballot(node < special || node >= a_twins) == 0ull)) {
+                bool want = false;
+                if (node == a_done) {
+                    c_segments++;
+                    V3 so = (FEAT & F_XFORM) ? ow : o, sd = (FEAT & F_XFORM) ? dw : d, L;
+                    const bool finished = shade_segment<FEAT>(sc, rd, so, sd, tm, ps, g, depth, make_uint2(__float_as_uint(tmax), hit_prim), L, c_light_rect, c_light_sphere);
+                    if (finished) {
+                        if (COUNT) c_samples++;
+                        if (finish_sample(rd, ps, g, sample, depth, L, so, sd, tm)) {
+                            rd.blocksum[ps.work] = Float4{ps.acc.x, ps.acc.y, ps.acc.z, 0.f};
+                            want = true;
+                        }
+                    }
+                    o = so; d = sd;
+                }
+                // regeneration: one atomic per wave for the lanes whose item is complete
+                const uint64_t wm = __ballot(want);
+                if (wm != 0ull) {
+                    uint32_t base = 0;
+                    if (lane == (uint32_t)__builtin_ctzll(wm)) base = atomicAdd(next_work, (uint32_t)__popcll(wm));
+                    base = (uint32_t)__shfl((int)base, __builtin_ctzll(wm));
+                    if (want) {
+                        const uint32_t work = base + lane_rank(wm);
+                        if (work < rd.total_items) { start_item(rd, work, ps, o, d, tm); g.s = ps.rng; depth = 0; sample = ps.sdepth >> 8; }
+                        else node = a_idle;                                  // nothing left: the lane retires
+                    }
+                }
+                if (node == a_done) begin_walk();
+            }
+            if (__ballot(node != a_idle) == 0ull) break;
+        } else {
         // next refill is due when enough lanes are idle and there is something to hand out, or nobody has a ray
         const uint64_t hv = __ballot(node != a_idle);
         if (hv == 0ull) break;
         if (n_cnt != 0u && 64 - (int)__popcll(hv) >= kRefillMin) break;
         }
+        }
+        if (DRAIN) break;
+    }
+    if (DRAIN) {
+        for (int off = 32; off > 0; off >>= 1) {
+            c_segments += __shfl_down(c_segments, off);
+            if (COUNT) { c_samples += __shfl_down(c_samples, off); c_light_rect += __shfl_down(c_light_rect, off); c_light_sphere += __shfl_down(c_light_sphere, off); }
+        }
+        if (lane == 0u) {
+            if (c_segments) atomicAdd(&counters[CTR_SEGMENTS], c_segments);
+            if (COUNT && c_samples) atomicAdd(&counters[CTR_SAMPLES], c_samples);
+            if (COUNT && c_light_rect) atomicAdd(&counters[CTR_PRIM_TESTS + 2], c_light_rect);
+            if (COUNT && c_light_sphere) atomicAdd(&counters[CTR_PRIM_TESTS + 0], c_light_sphere);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[CTR_ITERATIONS], 1ull);
     }
 #ifdef RT_STAMPS
     if ((threadIdx.x & 63u) == 0u) {
@@ -824,16 +926,6 @@ DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t s
     tm = g.range(rd.cam_time0, rd.cam_time1);                    // drawn even when time0 == time1
 }
 
-// L, the radiance of the sample in flight, is not part of the state: `emitted` is non-zero only for
-// DiffuseLight, which never scatters (material.rs:12-14,184-190), and the background is returned on a miss
-// (main.rs:74-76) — so radiance is only ever added by the event that ENDS the path, in the same k_shade call
-// that folds it into `acc`.
-struct PathState {
-    V3 T, acc;
-    uint32_t work, sdepth;       // sdepth = sample index << 8 | depth
-    uint32_t from;               // primitive id the ray starts on (hit-record id), 0 = none
-    uint64_t rng;
-};
 // 60 bytes per path: ray_o, ray_d, s0 = (T, work item), s3 = (rng, sample << 8 | depth) — the pixel is a function of the work item and is
 // decoded where it is needed (a new sample of a multi-sample item, the key of the medium draws), not carried; the running sum
 // `acc` (s1, +16 bytes) exists only when a work item is more than one sample (with_acc = block_shift != 0).
@@ -994,6 +1086,199 @@ DEVI void sphere_uv(V3 p, float& u, float& v) {                                /
     v = theta * kInvPi;
 }
 
+// One segment's worth of ray_color (main.rs:74-138) after world.hit: from the hit record to either the end of the sample
+// (returns true, L = its radiance) or the next ray (o, d, tm, s.T, s.from, depth updated). Shared by k_shade and the drain loop of
+// k_extend so that a path computes the same numbers whichever kernel carries it.
+template <uint32_t FEAT>
+DEVI bool shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& d, float& tm, PathState& s, Rng& g, uint32_t& depth, uint2 hit, V3& L,
+                        unsigned long long& c_light_rect, unsigned long long& c_light_sphere) {
+    bool finished = false;
+    L = v3(0.f, 0.f, 0.f);          // radiance of this sample: set by the terminal event only
+    if (hit.y == rtd::HIT_NONE) {
+        // main.rs:74-76: the miss returns the background
+        V3 bg = v3(rd.bg[0], rd.bg[1], rd.bg[2]);
+        if (rd.bg_mode == RT_BG_SKY_GRADIENT_K) {
+            const V3 ud = unit(d);
+            const float t = 0.5f * (ud.y + 1.0f);
+            bg = (1.0f - t) * v3(1.f, 1.f, 1.f) + t * bg;
+        }
+        L = s.T * bg;
+        finished = true;
+    } else {
+        // ---- rebuild the HitRecord (hittable.rs:11-19) from (ray, t, primitive) ----
+        const float t = __uint_as_float(hit.x);
+        const uint32_t type = hit.y >> 28, idx = hit.y & rtd::LEAF_MAX_FIRST;
+        uint32_t meta;
+        V3 p, n; float hu = 0.f, hv = 0.f; bool ff;
+        if ((FEAT & F_MEDIUM) && type == rtd::LT_MEDIUM) {
+            meta = sc.media[idx].meta;
+            p = o + d * t; n = v3(1.f, 0.f, 0.f); ff = true;                // constant_medium.rs:62-66
+        } else {
+            meta = type == rtd::LT_SPHERE ? sc.sphere_meta[idx]
+                 : ((FEAT & F_RECT) && type == rtd::LT_RECT) ? sc.rect_meta[idx]
+                 : ((FEAT & F_MOVING) && type == rtd::LT_MOVING) ? sc.moving_meta[idx]
+                 : ((FEAT & F_TRI) && type == rtd::LT_TRI) ? sc.tri_meta[idx] : 0u;
+            const uint32_t wrap = (FEAT & F_XFORM) ? (meta >> 22) : 0u;
+            rtd::Wrap W{};
+            if ((FEAT & F_XFORM) && wrap) W = sc.wraps[wrap];
+            const uint32_t xf = W.xform;
+            V3 ol = o, dl = d;
+            if ((FEAT & F_XFORM) && xf) xform_ray(sc.xforms[xf], o, d, ol, dl);
+            V3 outward;
+            if (type == rtd::LT_SPHERE) {
+                const Float4 sp = sc.spheres[idx];
+                p = ol + dl * t;                                            // sphere.rs:59
+                outward = (p - v3(sp.x, sp.y, sp.z)) / sp.w;                // :60
+                if (FEAT & F_TEX) sphere_uv(outward, hu, hv);               // :62 (only textures read u,v)
+            } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
+                const Float4 r0 = sc.rects[2 * idx], r1 = sc.rects[2 * idx + 1];
+                const int kaxis = (int)r1.y; const int ia = kaxis == 0 ? 1 : 0, ib = kaxis == 2 ? 1 : 2;
+                p = ol + dl * t;                                            // aarect.rs:46
+                const float a = comp(p, ia), b = comp(p, ib);
+                hu = fdiv(a - r0.x, r0.y - r0.x); hv = fdiv(b - r0.z, r0.w - r0.z);   // :41-42
+                // on the plane exactly: the f64 reference's r.at(t) lands within 1e-13 of k
+                if (kaxis == 0) p.x = r1.x; else if (kaxis == 1) p.y = r1.x; else p.z = r1.x;
+                outward = v3(kaxis == 0 ? 1.f : 0.f, kaxis == 1 ? 1.f : 0.f, kaxis == 2 ? 1.f : 0.f);
+            } else if ((FEAT & F_MOVING) && type == rtd::LT_MOVING) {
+                const Float4 m0 = sc.moving[3 * idx], m1 = sc.moving[3 * idx + 1], m2 = sc.moving[3 * idx + 2];
+                p = ol + dl * t;
+                outward = (p - moving_center(m0, m1, m2, tm)) / m0.w;       // moving_sphere.rs:58 (u,v not set: 0)
+            } else {
+                const V3 v0 = f4xyz(sc.tris[3 * idx]), v1 = f4xyz(sc.tris[3 * idx + 1]), v2 = f4xyz(sc.tris[3 * idx + 2]);
+                float tt, bu, bv;
+                tri_hit(ol, dl, v0, v1, v2, -kInf, kInf, tt, bu, bv);
+                hu = bu; hv = bv;
+                p = ol + dl * t;
+                outward = unit(cross(v1 - v0, v2 - v0));
+            }
+            ff = dot(dl, outward) < 0.f;                                    // set_face_normal, hittable.rs:41-48
+            n = ff ? outward : -outward;
+            if ((FEAT & F_XFORM) && wrap) {
+                if (xf) p = xform_point_back(sc.xforms[xf], p);
+                // Replay the wrappers from the innermost out. dirs: the ray direction each wrapper hands to
+                // its child (Translate keeps it, RotateY rotates it, hittable.rs:154-155).
+                V3 dk[rtd::MAX_WRAP_OPS + 1];
+                dk[0] = d;
+#pragma unroll
+                for (uint32_t k = 0; k < rtd::MAX_WRAP_OPS; ++k) {
+                    const float sn = W.op[k].sin_t, cs = W.op[k].cos_t;
+                    const V3 q = dk[k];
+                    dk[k + 1] = (k < W.n_ops && W.op[k].kind == rtd::WO_ROTATE_Y) ? v3(cs * q.x - sn * q.z, q.y, sn * q.x + cs * q.z) : q;
+                }
+#pragma unroll
+                for (int k = (int)rtd::MAX_WRAP_OPS - 1; k >= 0; --k) {
+                    if ((uint32_t)k < W.n_ops) {
+                        const uint32_t kind = W.op[k].kind;
+                        if (kind == rtd::WO_FLIP_FACE) ff = !ff;                                   // hittable.rs:199
+                        else {
+                            if (kind == rtd::WO_ROTATE_Y) {                                        // hittable.rs:169-170
+                                const float sn = W.op[k].sin_t, cs = W.op[k].cos_t;
+                                n = v3(cs * n.x + sn * n.z, n.y, -sn * n.x + cs * n.z);
+                            }
+                            ff = dot(dk[k + 1], n) < 0.f;                                          // hittable.rs:82-83 / 173
+                            n = ff ? n : -n;
+                        }
+                    }
+                }
+            }
+        }
+        const uint32_t mat = meta & rtd::META_MAT_MASK;
+        const Float4 ma = sc.mat_a[mat]; const uint32_t mb = sc.mat_b[mat];
+        const uint32_t kind = mb & 15u, tex = mb >> 4;
+        // the next ray starts on this primitive (not for a medium: its hit point is inside the volume; not for a
+        // Metal bounce off a moving sphere: Metal resets the ray's time to 0, which moves the sphere)
+        s.from = (type == rtd::LT_MEDIUM || (type == rtd::LT_MOVING && kind == rtd::MK_METAL)) ? 0u : hit.y;
+        V3 colour = v3(ma.x, ma.y, ma.z);
+        if ((FEAT & F_TEX) && tex != rtd::TEX_INLINE && kind != rtd::MK_METAL && kind != rtd::MK_DIELECTRIC) colour = texture_value(sc, tex, hu, hv, p);
+
+        if (kind == rtd::MK_DIFFUSE_LIGHT) {
+            // emitted (material.rs:184-190); default scatter returns false -> main.rs:85-87
+            if (ff) L = s.T * colour;
+            finished = true;
+        } else {
+            if (kind == rtd::MK_LAMBERTIAN) {
+                // Lambertian::scatter (material.rs:48-63): attenuation = albedo, pdf = CosinePdf(normal)
+                const Onb uvw = onb_from_w(n);                              // pdf.rs:18-22
+                V3 dir;
+                float pdf_val;
+                if ((FEAT & F_LIGHTS) && sc.n_lights) {
+                    // MixturePdf::generate (pdf.rs:73-79) over HittablePdf(lights) and the cosine pdf
+                    if (g.rnd() < 0.5f) {
+                        const uint32_t k = (uint32_t)(g.next64() % (uint64_t)sc.n_lights);   // hittable_list.rs:81-84
+                        dir = light_random(sc.lights[k], p, g);
+                    } else dir = onb_local(uvw, random_cosine_direction(g));
+                    // MixturePdf::value (pdf.rs:70-72)
+                    const float weight = 1.0f / (float)sc.n_lights;
+                    float lsum = 0.f;
+                    for (uint32_t k = 0; k < sc.n_lights; ++k) {
+                        const rtd::Light l = sc.lights[k];
+                        lsum += weight * light_pdf_value(l, p, dir, l.kind == rtd::LK_XZRECT ? c_light_rect : c_light_sphere);
+                    }
+                    const float cosine = dot(unit(dir), uvw.w);
+                    const float cpdf = cosine <= 0.f ? 0.f : cosine * kInvPi;   // pdf.rs:24-31
+                    pdf_val = 0.5f * lsum + 0.5f * cpdf;
+                } else {
+                    dir = onb_local(uvw, random_cosine_direction(g));       // pdf.rs:32-34
+                    const float cosine = dot(unit(dir), uvw.w);
+                    pdf_val = cosine <= 0.f ? 0.f : cosine * kInvPi;
+                }
+                const float cosine_s = dot(n, unit(dir));                   // scattering_pdf, material.rs:64-71
+                const float spdf = cosine_s < 0.f ? 0.f : cosine_s * kInvPi;
+                s.T = s.T * colour * fdiv(spdf, pdf_val);                   // main.rs:130-138 (emitted = 0)
+                o = p; d = dir;                                             // main.rs:96 (time kept)
+            } else if (kind == rtd::MK_METAL) {
+                // Metal::scatter (material.rs:96-107): the fuzz sphere is drawn even for fuzz 0; time := 0.0
+                const V3 reflected = reflect(unit(d), n);
+                const V3 fz = random_in_unit_sphere(g);
+                s.T = s.T * colour;                                         // main.rs:89-92
+                o = p; d = reflected + ma.w * fz; tm = 0.0f;
+            } else if (kind == rtd::MK_DIELECTRIC) {
+                // Dielectric::scatter (material.rs:131-155)
+                const float ir = ma.w;
+                const float ratio = ff ? fdiv(1.0f, ir) : ir;
+                const V3 ud = unit(d);
+                const float cos_theta = fminf(dot(-ud, n), 1.0f);
+                const float sin_theta = fsqrt(1.0f - cos_theta * cos_theta);
+                const bool cannot_refract = ratio * sin_theta > 1.0f;
+                bool refl = cannot_refract;
+                if (!refl) {                                                // `||` short-circuit: draw only if it can refract
+                    float r0 = fdiv(1.f - ratio, 1.f + ratio); r0 *= r0;
+                    const float m = 1.f - cos_theta;
+                    const float reflectance = r0 + (1.f - r0) * (m * m * m * m * m);   // material.rs:123-127
+                    refl = reflectance > g.rnd();
+                }
+                d = refl ? reflect(ud, n) : refract(ud, n, ratio);
+                o = p;
+            } else {
+                // Isotropic::scatter (material.rs:209-219, commented spec)
+                const V3 dir = random_in_unit_sphere(g);
+                s.T = s.T * colour;
+                o = p; d = dir;
+            }
+            depth++;
+            if (depth >= rd.max_depth) finished = true;                     // main.rs:71-73: the next call returns 0
+        }
+    }
+
+    return finished;
+}
+
+// The end of a sample (main.rs:772 `pixel_color += received`): fold L into the work item's sum, move to the item's next sample or
+// report the item complete (true; the caller stores s.acc and draws new work).
+DEVI bool finish_sample(const RenderDev& rd, PathState& s, Rng& g, uint32_t& sample, uint32_t& depth, V3 L, V3& o, V3& d, float& tm) {
+    const bool fin_ok = (fabsf(L.x) < kInf) && (fabsf(L.y) < kInf) && (fabsf(L.z) < kInf);
+    if (!fin_ok && rd.nan_policy == RT_NAN_PER_SAMPLE_K) L = v3(0.f, 0.f, 0.f);
+    s.acc = s.acc + L;
+    sample++;
+    if ((sample & ((1u << rd.block_shift) - 1u)) != 0u && sample < rd.spp) {
+        const WorkItem it = decode_work(rd, s.work);
+        new_camera_ray(rd, it.x, it.y, sample, g, o, d, tm);   // next sample of the same block
+        s.T = v3(1, 1, 1); depth = 0; s.from = 0u;
+        return false;
+    }
+    return true;
+}
+
 template <uint32_t FEAT, bool COUNT>
 __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in, PoolDev out, RenderDev rd, const uint32_t* __restrict__ count_in_ptr,
                                                 uint32_t* __restrict__ count_out, uint32_t* __restrict__ next_work, uint32_t* __restrict__ head_to_zero,
@@ -1023,184 +1308,12 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
         uint32_t depth = s.sdepth & 0xFFu, sample = s.sdepth >> 8;
         bool finished = false;
 
-        if (hit.y == rtd::HIT_NONE) {
-            // main.rs:74-76: the miss returns the background
-            V3 bg = v3(rd.bg[0], rd.bg[1], rd.bg[2]);
-            if (rd.bg_mode == RT_BG_SKY_GRADIENT_K) {
-                const V3 ud = unit(d);
-                const float t = 0.5f * (ud.y + 1.0f);
-                bg = (1.0f - t) * v3(1.f, 1.f, 1.f) + t * bg;
-            }
-            L = s.T * bg;
-            finished = true;
-        } else {
-            // ---- rebuild the HitRecord (hittable.rs:11-19) from (ray, t, primitive) ----
-            const float t = __uint_as_float(hit.x);
-            const uint32_t type = hit.y >> 28, idx = hit.y & rtd::LEAF_MAX_FIRST;
-            uint32_t meta;
-            V3 p, n; float hu = 0.f, hv = 0.f; bool ff;
-            if ((FEAT & F_MEDIUM) && type == rtd::LT_MEDIUM) {
-                meta = sc.media[idx].meta;
-                p = o + d * t; n = v3(1.f, 0.f, 0.f); ff = true;                // constant_medium.rs:62-66
-            } else {
-                meta = type == rtd::LT_SPHERE ? sc.sphere_meta[idx]
-                     : ((FEAT & F_RECT) && type == rtd::LT_RECT) ? sc.rect_meta[idx]
-                     : ((FEAT & F_MOVING) && type == rtd::LT_MOVING) ? sc.moving_meta[idx]
-                     : ((FEAT & F_TRI) && type == rtd::LT_TRI) ? sc.tri_meta[idx] : 0u;
-                const uint32_t wrap = (FEAT & F_XFORM) ? (meta >> 22) : 0u;
-                rtd::Wrap W{};
-                if ((FEAT & F_XFORM) && wrap) W = sc.wraps[wrap];
-                const uint32_t xf = W.xform;
-                V3 ol = o, dl = d;
-                if ((FEAT & F_XFORM) && xf) xform_ray(sc.xforms[xf], o, d, ol, dl);
-                V3 outward;
-                if (type == rtd::LT_SPHERE) {
-                    const Float4 sp = sc.spheres[idx];
-                    p = ol + dl * t;                                            // sphere.rs:59
-                    outward = (p - v3(sp.x, sp.y, sp.z)) / sp.w;                // :60
-                    if (FEAT & F_TEX) sphere_uv(outward, hu, hv);               // :62 (only textures read u,v)
-                } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
-                    const Float4 r0 = sc.rects[2 * idx], r1 = sc.rects[2 * idx + 1];
-                    const int kaxis = (int)r1.y; const int ia = kaxis == 0 ? 1 : 0, ib = kaxis == 2 ? 1 : 2;
-                    p = ol + dl * t;                                            // aarect.rs:46
-                    const float a = comp(p, ia), b = comp(p, ib);
-                    hu = fdiv(a - r0.x, r0.y - r0.x); hv = fdiv(b - r0.z, r0.w - r0.z);   // :41-42
-                    // on the plane exactly: the f64 reference's r.at(t) lands within 1e-13 of k
-                    if (kaxis == 0) p.x = r1.x; else if (kaxis == 1) p.y = r1.x; else p.z = r1.x;
-                    outward = v3(kaxis == 0 ? 1.f : 0.f, kaxis == 1 ? 1.f : 0.f, kaxis == 2 ? 1.f : 0.f);
-                } else if ((FEAT & F_MOVING) && type == rtd::LT_MOVING) {
-                    const Float4 m0 = sc.moving[3 * idx], m1 = sc.moving[3 * idx + 1], m2 = sc.moving[3 * idx + 2];
-                    p = ol + dl * t;
-                    outward = (p - moving_center(m0, m1, m2, tm)) / m0.w;       // moving_sphere.rs:58 (u,v not set: 0)
-                } else {
-                    const V3 v0 = f4xyz(sc.tris[3 * idx]), v1 = f4xyz(sc.tris[3 * idx + 1]), v2 = f4xyz(sc.tris[3 * idx + 2]);
-                    float tt, bu, bv;
-                    tri_hit(ol, dl, v0, v1, v2, -kInf, kInf, tt, bu, bv);
-                    hu = bu; hv = bv;
-                    p = ol + dl * t;
-                    outward = unit(cross(v1 - v0, v2 - v0));
-                }
-                ff = dot(dl, outward) < 0.f;                                    // set_face_normal, hittable.rs:41-48
-                n = ff ? outward : -outward;
-                if ((FEAT & F_XFORM) && wrap) {
-                    if (xf) p = xform_point_back(sc.xforms[xf], p);
-                    // Replay the wrappers from the innermost out. dirs: the ray direction each wrapper hands to
-                    // its child (Translate keeps it, RotateY rotates it, hittable.rs:154-155).
-                    V3 dk[rtd::MAX_WRAP_OPS + 1];
-                    dk[0] = d;
-#pragma unroll
-                    for (uint32_t k = 0; k < rtd::MAX_WRAP_OPS; ++k) {
-                        const float sn = W.op[k].sin_t, cs = W.op[k].cos_t;
-                        const V3 q = dk[k];
-                        dk[k + 1] = (k < W.n_ops && W.op[k].kind == rtd::WO_ROTATE_Y) ? v3(cs * q.x - sn * q.z, q.y, sn * q.x + cs * q.z) : q;
-                    }
-#pragma unroll
-                    for (int k = (int)rtd::MAX_WRAP_OPS - 1; k >= 0; --k) {
-                        if ((uint32_t)k < W.n_ops) {
-                            const uint32_t kind = W.op[k].kind;
-                            if (kind == rtd::WO_FLIP_FACE) ff = !ff;                                   // hittable.rs:199
-                            else {
-                                if (kind == rtd::WO_ROTATE_Y) {                                        // hittable.rs:169-170
-                                    const float sn = W.op[k].sin_t, cs = W.op[k].cos_t;
-                                    n = v3(cs * n.x + sn * n.z, n.y, -sn * n.x + cs * n.z);
-                                }
-                                ff = dot(dk[k + 1], n) < 0.f;                                          // hittable.rs:82-83 / 173
-                                n = ff ? n : -n;
-                            }
-                        }
-                    }
-                }
-            }
-            const uint32_t mat = meta & rtd::META_MAT_MASK;
-            const Float4 ma = sc.mat_a[mat]; const uint32_t mb = sc.mat_b[mat];
-            const uint32_t kind = mb & 15u, tex = mb >> 4;
-            // the next ray starts on this primitive (not for a medium: its hit point is inside the volume; not for a
-            // Metal bounce off a moving sphere: Metal resets the ray's time to 0, which moves the sphere)
-            s.from = (type == rtd::LT_MEDIUM || (type == rtd::LT_MOVING && kind == rtd::MK_METAL)) ? 0u : hit.y;
-            V3 colour = v3(ma.x, ma.y, ma.z);
-            if ((FEAT & F_TEX) && tex != rtd::TEX_INLINE && kind != rtd::MK_METAL && kind != rtd::MK_DIELECTRIC) colour = texture_value(sc, tex, hu, hv, p);
-
-            if (kind == rtd::MK_DIFFUSE_LIGHT) {
-                // emitted (material.rs:184-190); default scatter returns false -> main.rs:85-87
-                if (ff) L = s.T * colour;
-                finished = true;
-            } else {
-                if (kind == rtd::MK_LAMBERTIAN) {
-                    // Lambertian::scatter (material.rs:48-63): attenuation = albedo, pdf = CosinePdf(normal)
-                    const Onb uvw = onb_from_w(n);                              // pdf.rs:18-22
-                    V3 dir;
-                    float pdf_val;
-                    if ((FEAT & F_LIGHTS) && sc.n_lights) {
-                        // MixturePdf::generate (pdf.rs:73-79) over HittablePdf(lights) and the cosine pdf
-                        if (g.rnd() < 0.5f) {
-                            const uint32_t k = (uint32_t)(g.next64() % (uint64_t)sc.n_lights);   // hittable_list.rs:81-84
-                            dir = light_random(sc.lights[k], p, g);
-                        } else dir = onb_local(uvw, random_cosine_direction(g));
-                        // MixturePdf::value (pdf.rs:70-72)
-                        const float weight = 1.0f / (float)sc.n_lights;
-                        float lsum = 0.f;
-                        for (uint32_t k = 0; k < sc.n_lights; ++k) {
-                            const rtd::Light l = sc.lights[k];
-                            lsum += weight * light_pdf_value(l, p, dir, l.kind == rtd::LK_XZRECT ? c_light_rect : c_light_sphere);
-                        }
-                        const float cosine = dot(unit(dir), uvw.w);
-                        const float cpdf = cosine <= 0.f ? 0.f : cosine * kInvPi;   // pdf.rs:24-31
-                        pdf_val = 0.5f * lsum + 0.5f * cpdf;
-                    } else {
-                        dir = onb_local(uvw, random_cosine_direction(g));       // pdf.rs:32-34
-                        const float cosine = dot(unit(dir), uvw.w);
-                        pdf_val = cosine <= 0.f ? 0.f : cosine * kInvPi;
-                    }
-                    const float cosine_s = dot(n, unit(dir));                   // scattering_pdf, material.rs:64-71
-                    const float spdf = cosine_s < 0.f ? 0.f : cosine_s * kInvPi;
-                    s.T = s.T * colour * fdiv(spdf, pdf_val);                   // main.rs:130-138 (emitted = 0)
-                    o = p; d = dir;                                             // main.rs:96 (time kept)
-                } else if (kind == rtd::MK_METAL) {
-                    // Metal::scatter (material.rs:96-107): the fuzz sphere is drawn even for fuzz 0; time := 0.0
-                    const V3 reflected = reflect(unit(d), n);
-                    const V3 fz = random_in_unit_sphere(g);
-                    s.T = s.T * colour;                                         // main.rs:89-92
-                    o = p; d = reflected + ma.w * fz; tm = 0.0f;
-                } else if (kind == rtd::MK_DIELECTRIC) {
-                    // Dielectric::scatter (material.rs:131-155)
-                    const float ir = ma.w;
-                    const float ratio = ff ? fdiv(1.0f, ir) : ir;
-                    const V3 ud = unit(d);
-                    const float cos_theta = fminf(dot(-ud, n), 1.0f);
-                    const float sin_theta = fsqrt(1.0f - cos_theta * cos_theta);
-                    const bool cannot_refract = ratio * sin_theta > 1.0f;
-                    bool refl = cannot_refract;
-                    if (!refl) {                                                // `||` short-circuit: draw only if it can refract
-                        float r0 = fdiv(1.f - ratio, 1.f + ratio); r0 *= r0;
-                        const float m = 1.f - cos_theta;
-                        const float reflectance = r0 + (1.f - r0) * (m * m * m * m * m);   // material.rs:123-127
-                        refl = reflectance > g.rnd();
-                    }
-                    d = refl ? reflect(ud, n) : refract(ud, n, ratio);
-                    o = p;
-                } else {
-                    // Isotropic::scatter (material.rs:209-219, commented spec)
-                    const V3 dir = random_in_unit_sphere(g);
-                    s.T = s.T * colour;
-                    o = p; d = dir;
-                }
-                depth++;
-                if (depth >= rd.max_depth) finished = true;                     // main.rs:71-73: the next call returns 0
-            }
-        }
+        finished = shade_segment<FEAT>(sc, rd, o, d, tm, s, g, depth, hit, L, c_light_rect, c_light_sphere);
 
         if (finished) {
-            // one sample done: main.rs:772 `pixel_color += received`
+            // one sample done
             if (COUNT) c_samples++;
-            const bool fin_ok = (fabsf(L.x) < kInf) && (fabsf(L.y) < kInf) && (fabsf(L.z) < kInf);
-            if (!fin_ok && rd.nan_policy == RT_NAN_PER_SAMPLE_K) L = v3(0.f, 0.f, 0.f);
-            s.acc = s.acc + L;
-            sample++;
-            if ((sample & ((1u << rd.block_shift) - 1u)) != 0u && sample < rd.spp) {
-                const WorkItem it = decode_work(rd, s.work);
-                new_camera_ray(rd, it.x, it.y, sample, g, o, d, tm);   // next sample of the same block
-                s.T = v3(1, 1, 1); depth = 0; s.from = 0u;
-            } else {
+            if (finish_sample(rd, s, g, sample, depth, L, o, d, tm)) {
                 rd.blocksum[s.work] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
                 want_work = true;
             }
@@ -1292,7 +1405,16 @@ __global__ void __launch_bounds__(256) k_untile(const T* __restrict__ gathered, 
 template <int MODE, uint32_t FEAT, bool COUNT, uint32_t TPB>
 static hipError_t launch_extend_g(uint32_t n_groups, size_t lds_bytes, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
-    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, TPB>), dim3(n_groups), dim3(TPB), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
+    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, TPB, false>), dim3(n_groups), dim3(TPB), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd, (uint32_t*)nullptr);
+    return hipGetLastError();
+}
+// the drain form: one lane per path of the pool (upper bound max_count; the kernel reads the real count), 256-thread groups
+template <int MODE, uint32_t FEAT, bool COUNT>
+static hipError_t launch_drain_c(const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, uint32_t max_count, const uint32_t* count_ptr, uint32_t* head, uint32_t* cz,
+                                 uint32_t* next_work, unsigned long long* counters, hipStream_t stream) {
+    const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
+    constexpr uint32_t T = kExtendThreads;
+    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, T, true>), dim3((max_count + T - 1u) / T), dim3(T), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd, next_work);
     return hipGetLastError();
 }
 template <int MODE, uint32_t FEAT, bool COUNT>
@@ -1304,13 +1426,13 @@ static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, cons
     constexpr uint32_t T0 = kExtendThreads, T1 = MODE == M_HBM ? T0 : 2u * T0, T2 = MODE == M_HBM ? T0 : 4u * T0;
     static thread_local size_t cached_lds = ~(size_t)0; static thread_local int nb[3] = {0, 0, 0}; static thread_local int pick = 0;
     if (cached_lds != lds_bytes) {
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[0], k_extend<MODE, FEAT, COUNT, T0>, (int)T0, lds_bytes);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[0], k_extend<MODE, FEAT, COUNT, T0, false>, (int)T0, lds_bytes);
         if (e != hipSuccess) return e;
         nb[1] = nb[2] = 0;
         if (MODE != M_HBM) {
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[1], k_extend<MODE, FEAT, COUNT, T1>, (int)T1, lds_bytes);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[1], k_extend<MODE, FEAT, COUNT, T1, false>, (int)T1, lds_bytes);
             if (e != hipSuccess) return e;
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[2], k_extend<MODE, FEAT, COUNT, T2>, (int)T2, lds_bytes);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[2], k_extend<MODE, FEAT, COUNT, T2, false>, (int)T2, lds_bytes);
             if (e != hipSuccess) return e;
         }
 #ifdef RT_EXTEND_PER_CU_MAX
@@ -1359,6 +1481,20 @@ hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev
     return RT_EXT_V(M_HBM);
 #undef RT_EXT_V
 #undef RT_EXT
+}
+
+hipError_t launch_drain(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, uint32_t max_count, const uint32_t* count_ptr,
+                        uint32_t* head, uint32_t* cz, uint32_t* next_work, unsigned long long* counters, bool count, hipStream_t stream) {
+    if (max_count == 0u) return hipSuccess;
+    const uint32_t v = pick_variant(cfg.features);
+#define RT_DRN(M, F) (count ? launch_drain_c<M, F, true>(sc, pool, rd, max_count, count_ptr, head, cz, next_work, counters, stream) \
+                            : launch_drain_c<M, F, false>(sc, pool, rd, max_count, count_ptr, head, cz, next_work, counters, stream))
+#define RT_DRN_V(M) (v == 0u ? RT_DRN(M, 0u) : v == kVariantMesh ? RT_DRN(M, kVariantMesh) : v == kVariantBox ? RT_DRN(M, kVariantBox) : RT_DRN(M, F_ALL))
+    if (cfg.scene_in_lds) return RT_DRN_V(M_LDS);
+    if (sc.n_top != 0u) return RT_DRN_V(M_TOP);
+    return RT_DRN_V(M_HBM);
+#undef RT_DRN_V
+#undef RT_DRN
 }
 
 template <uint32_t FEAT>

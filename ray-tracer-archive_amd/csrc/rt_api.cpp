@@ -419,7 +419,12 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     std::vector<Pending> pending;      // oldest first
     size_t pending_head = 0;
     auto take = [&](const Pending& pd_) { live = std::min(live, ctx->h_count[pd_.ring]); };
-    uint32_t launched = 0;
+    // The tail goes to the drain kernel: once at most `drain_at` paths are alive, ONE launch carries each of them to its end
+    // (kernels.hip DRAIN). RT_FLAG_FUSED hands the whole render to it (a diagnostic: bit-identical frame, slower).
+    uint32_t drain_at = 1u << 21;
+    if (const char* e = getenv("RT_DRAIN_AT")) drain_at = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (prm->flags & RT_FLAG_FUSED) drain_at = 0xFFFFFFFFu;
+    uint32_t launched = 0, drained = 0;
     while (live > 0) {
         while (pending_head < pending.size() && hipEventQuery(pending[pending_head].ev) == hipSuccess) take(pending[pending_head++]);
         if (live == 0) break;
@@ -427,6 +432,14 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
             HIP_TRY(ctx, hipEventSynchronize(pending[pending_head].ev));
             take(pending[pending_head++]);
             if (live == 0) break;
+        }
+        if (live <= drain_at) {
+            hipEvent_t ea = nullptr, eb = nullptr;
+            if (timing) HIP_TRY(ctx, next_event(ea));
+            HIP_TRY(ctx, rtk::launch_drain(cfg, scene->dev, pd[cur], rd, live, c_count[cur], c_head, c_count[1 - cur], c_next_work, c64, counting, ctx->stream));
+            if (timing) { HIP_TRY(ctx, next_event(eb)); spans.push_back({ea, eb, 3}); }
+            drained = live;
+            break;
         }
         hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
         if (timing) HIP_TRY(ctx, next_event(ea));
@@ -455,7 +468,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         stats->render_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
         for (const Span& s : spans) {
             float ms = 0.f; if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) continue;
-            if (s.kind == 0) stats->extend_ms += ms; else if (s.kind == 1) stats->shade_ms += ms; else stats->other_ms += ms;
+            if (s.kind == 0) stats->extend_ms += ms; else if (s.kind == 1) stats->shade_ms += ms; else if (s.kind == 3) stats->drain_ms += ms; else stats->other_ms += ms;
         }
         stats->samples = valid_pixels * rd.spp;
         stats->segments = ctx->h_counters[rtk::CTR_SEGMENTS];
@@ -466,7 +479,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         for (int k = 0; k < 5; ++k) stats->debug[k] = ctx->h_counters[rtk::CTR_DEBUG + k];
         stats->debug[6] = extend_geometry[0]; stats->debug[7] = extend_geometry[1];   // k_extend: threads per workgroup, resident workgroups per CU
         stats->iterations = (uint32_t)ctx->h_counters[rtk::CTR_ITERATIONS]; stats->extend_launches = launched; stats->shade_launches = launched; stats->pool_slots = P;
-        stats->n_devices = 1u; stats->lds_top_nodes = scene->dev.n_top;
+        stats->n_devices = 1u; stats->lds_top_nodes = scene->dev.n_top; stats->drain_paths = drained;
         stats->scene_nodes = scene->n_nodes; stats->scene_prims = scene->n_prims; stats->scene_bytes = scene->bytes; stats->bvh_in_lds = scene->in_lds ? 1u : 0u;
     }
     return RT_OK;

@@ -216,3 +216,42 @@ def test_parameter_corners_are_pool_independent(pkg, gpu):
             assert sa["samples"] == sb["samples"] == W * H * spp and sa["segments"] == sb["segments"]
             if depth == 1:
                 assert sa["segments"] == W * H * spp      # one world.hit per sample
+
+
+def test_drain_kernel_is_bit_identical(pkg, gpu, earth):
+    """The tail of a render is carried by ONE fused launch (one lane per path: walk, shade in place, next ray, new work while there is
+    any). Wherever the hand-over happens — never (RT_DRAIN_AT=0), at the default, or at the first ray (RT_FLAG_FUSED: the whole
+    render by that kernel, including its own regeneration from a tiny pool) — the frame, the sample count and the segment count are
+    the same, on every kernel feature set: spheres only, rects + instance transforms + lights, media + textures + moving spheres."""
+    import os
+    A = pkg._abi
+    SB = A.RT_FLAG_SAMPLE_BLOCKS
+    cases = [("book1", {}, 120, 80, 6), ("cornell", {}, 64, 64, 5), ("cornell_smoke", {}, 48, 48, 4), ("final", {"image": earth}, 56, 56, 3), ("book1_ref", {}, 64, 40, 4)]
+    old = os.environ.get("RT_DRAIN_AT")
+    try:
+        for name, kw, W, H, spp in cases:
+            hs = pkg.HostScene(name, 1, **kw)
+            scene = gpu.upload(hs.desc)
+            cam = hs.camera(W / H)
+            os.environ["RT_DRAIN_AT"] = "0"
+            ref, sr = gpu.render(scene, cam, pkg.make_params(W, H, spp, seed=3, flags=A.RT_FLAG_COUNTERS))
+            assert sr["drain_paths"] == 0
+            for drain_at, flags, pool in [("64", 0, 0), ("1000", 0, 0), ("100000000", 0, 0), ("0", A.RT_FLAG_FUSED, 0), ("0", A.RT_FLAG_FUSED, 256), ("300", 0, 512)]:
+                os.environ["RT_DRAIN_AT"] = drain_at
+                img, st = gpu.render(scene, cam, pkg.make_params(W, H, spp, seed=3, flags=flags | A.RT_FLAG_COUNTERS, pool_slots=pool))
+                assert st["drain_paths"] > 0, (name, drain_at, flags, pool)
+                assert np.array_equal(img, ref), (name, drain_at, flags, pool)
+                assert st["samples"] == sr["samples"] and st["segments"] == sr["segments"], (name, drain_at, flags, pool)
+                assert st["node_tests"] == sr["node_tests"] and st["prim_tests"] == sr["prim_tests"], (name, drain_at, flags, pool)
+            # multi-sample work items: the drain regenerates camera rays inside an item and carries its running sum
+            os.environ["RT_DRAIN_AT"] = "0"
+            a16, _ = gpu.render(scene, cam, pkg.make_params(W, H, 20, seed=3, flags=SB))
+            os.environ["RT_DRAIN_AT"] = "500"
+            b16, st = gpu.render(scene, cam, pkg.make_params(W, H, 20, seed=3, flags=SB))
+            c16, _ = gpu.render(scene, cam, pkg.make_params(W, H, 20, seed=3, flags=SB | A.RT_FLAG_FUSED, pool_slots=256))
+            assert st["drain_paths"] > 0 and np.array_equal(a16, b16) and np.array_equal(a16, c16), name
+    finally:
+        if old is None:
+            os.environ.pop("RT_DRAIN_AT", None)
+        else:
+            os.environ["RT_DRAIN_AT"] = old
