@@ -470,8 +470,9 @@ constexpr int kLeafBatch = RT_LEAF_BATCH;
 // the frame is bit-identical wherever the hand-over happens.
 enum : int { M_HBM = 0, M_LDS = 1, M_TOP = 2 };
 struct PathState;
-template <uint32_t FEAT> DEVI bool shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& d, float& tm, PathState& s, Rng& g, uint32_t& depth, uint2 hit, V3& L,
-                                                 unsigned long long& c_light_rect, unsigned long long& c_light_sphere);
+enum : uint32_t { SH_FINISHED = 1u, SH_TIME_ZERO = 2u };
+template <uint32_t FEAT> DEVI uint32_t shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& d, float tm, PathState& s, Rng& g, uint32_t& depth, uint2 hit, V3& L,
+                                                     unsigned long long& c_light_rect, unsigned long long& c_light_sphere);
 DEVI bool finish_sample(const RenderDev& rd, PathState& s, Rng& g, uint32_t& sample, uint32_t& depth, V3 L, V3& o, V3& d, float& tm);
 DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, V3& o, V3& d, float& tm);
 // L, the radiance of the sample in flight, is not part of the state: `emitted` is non-zero only for
@@ -834,8 +835,9 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                 if (node == a_done) {
                     c_segments++;
                     V3 so = (FEAT & F_XFORM) ? ow : o, sd = (FEAT & F_XFORM) ? dw : d, L;
-                    const bool finished = shade_segment<FEAT>(sc, rd, so, sd, tm, ps, g, depth, make_uint2(__float_as_uint(tmax), hit_prim), L, c_light_rect, c_light_sphere);
-                    if (finished) {
+                    const uint32_t sh = shade_segment<FEAT>(sc, rd, so, sd, tm, ps, g, depth, make_uint2(__float_as_uint(tmax), hit_prim), L, c_light_rect, c_light_sphere);
+                    if (sh & SH_TIME_ZERO) tm = 0.0f;
+                    if (sh & SH_FINISHED) {
                         if (COUNT) c_samples++;
                         if (finish_sample(rd, ps, g, sample, depth, L, so, sd, tm)) {
                             rd.blocksum[ps.work] = Float4{ps.acc.x, ps.acc.y, ps.acc.z, 0.f};
@@ -1087,13 +1089,21 @@ DEVI void sphere_uv(V3 p, float& u, float& v) {                                /
 }
 
 // One segment's worth of ray_color (main.rs:74-138) after world.hit: from the hit record to either the end of the sample
-// (returns true, L = its radiance) or the next ray (o, d, tm, s.T, s.from, depth updated). Shared by k_shade and the drain loop of
+// (SH_FINISHED, L = its radiance) or the next ray (o, d, s.T, s.from, depth updated). Shared by k_shade and the drain loop of
 // k_extend so that a path computes the same numbers whichever kernel carries it.
+// The ray's time is an INPUT only: Metal's "scattered ray has time 0.0" (material.rs:101) comes back as the SH_TIME_ZERO flag and the
+// caller applies it. (With `float& tm` assigned in the Metal branch, hipcc 7.2 compiled the F_ALL instance of k_shade so that a
+// Dielectric bounce left the Schlick draw in tm — found as the wavefront frame differing from the drain kernel's and the oracle's on
+// scenes with glass and moving spheres; tests/test_gpu_scenes.py::test_time_survives_a_glass_bounce keeps watch.)
 template <uint32_t FEAT>
-DEVI bool shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& d, float& tm, PathState& s, Rng& g, uint32_t& depth, uint2 hit, V3& L,
-                        unsigned long long& c_light_rect, unsigned long long& c_light_sphere) {
-    bool finished = false;
+DEVI uint32_t shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& d, const float tm, PathState& s, Rng& g, uint32_t& depth, uint2 hit, V3& L,
+                            unsigned long long& c_light_rect, unsigned long long& c_light_sphere) {
+    bool finished = false, time_zero = false;
     L = v3(0.f, 0.f, 0.f);          // radiance of this sample: set by the terminal event only
+#ifdef RT_DEBUG_WORK
+    if (s.work == RT_DEBUG_WORK) printf("work %u depth %u o %.9g %.9g %.9g d %.9g %.9g %.9g tm %.9g hit t %.9g prim %08x T %g %g %g rng %llx from %08x\n", s.work, depth, o.x, o.y, o.z,
+                                        d.x, d.y, d.z, tm, __uint_as_float(hit.x), hit.y, s.T.x, s.T.y, s.T.z, (unsigned long long)g.s, s.from);
+#endif
     if (hit.y == rtd::HIT_NONE) {
         // main.rs:74-76: the miss returns the background
         V3 bg = v3(rd.bg[0], rd.bg[1], rd.bg[2]);
@@ -1231,7 +1241,7 @@ DEVI bool shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& d, f
                 const V3 reflected = reflect(unit(d), n);
                 const V3 fz = random_in_unit_sphere(g);
                 s.T = s.T * colour;                                         // main.rs:89-92
-                o = p; d = reflected + ma.w * fz; tm = 0.0f;
+                o = p; d = reflected + ma.w * fz; time_zero = true;
             } else if (kind == rtd::MK_DIELECTRIC) {
                 // Dielectric::scatter (material.rs:131-155)
                 const float ir = ma.w;
@@ -1260,7 +1270,10 @@ DEVI bool shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& d, f
         }
     }
 
-    return finished;
+#ifdef RT_DEBUG_WORK
+    if (s.work == RT_DEBUG_WORK) printf("   exit: finished %d o %.9g %.9g %.9g d %.9g %.9g %.9g tm %.9g from %08x\n", (int)finished, o.x, o.y, o.z, d.x, d.y, d.z, tm, s.from);
+#endif
+    return (finished ? SH_FINISHED : 0u) | (time_zero ? SH_TIME_ZERO : 0u);
 }
 
 // The end of a sample (main.rs:772 `pixel_color += received`): fold L into the work item's sum, move to the item's next sample or
@@ -1306,9 +1319,9 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
         s.rng = (uint64_t)s3.x | ((uint64_t)s3.y << 32);
         Rng g; g.s = s.rng;
         uint32_t depth = s.sdepth & 0xFFu, sample = s.sdepth >> 8;
-        bool finished = false;
-
-        finished = shade_segment<FEAT>(sc, rd, o, d, tm, s, g, depth, hit, L, c_light_rect, c_light_sphere);
+        const uint32_t sh = shade_segment<FEAT>(sc, rd, o, d, tm, s, g, depth, hit, L, c_light_rect, c_light_sphere);
+        const bool finished = (sh & SH_FINISHED) != 0u;
+        if (sh & SH_TIME_ZERO) tm = 0.0f;
 
         if (finished) {
             // one sample done

@@ -372,6 +372,8 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     }
     HIP_TRY(ctx, ctx->blocksum.ensure((size_t)total_items * 16));
     rd.blocksum = (rtd::Float4*)ctx->blocksum.p;
+    // diagnostic: RT_DEBUG_POISON=1 fills the per-item sums with NaN first, so an item no kernel ever finished shows up in the frame
+    if (const char* e = getenv("RT_DEBUG_POISON")) if (e[0] == '1') HIP_TRY(ctx, hipMemsetAsync(ctx->blocksum.p, 0xFF, (size_t)total_items * 16, ctx->stream));
     HIP_TRY(ctx, ctx->tile_prefix.ensure(prefix.size() * 4));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->tile_prefix.p, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `prefix` is a stack vector

@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {
     "base": [],
+    "dbgwork": ["RT_DEBUG_WORK=3000u"],
+    "b1r1s1": ["RT_LEAF_BATCH=1", "RT_REFILL_MIN=1", "RT_STEPS=1"],
+    "b64": ["RT_LEAF_BATCH=64"],
     "f64only": ["RT_SPHERE_F64_ONLY=1"],
     "tol6": ["RT_SPHERE_TOL=1e-6f"],
     "tol4": ["RT_SPHERE_TOL=1e-4f"],

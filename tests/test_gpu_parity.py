@@ -1,9 +1,9 @@
 """Parity of the HIP path with the CPU oracle — the tests proper (-m gpu, through the C ABI).
 
 Stated tolerance (floating point path; the reference computes in f64, the device in f32):
-  * same seed, GPU vs f64 oracle: mean |diff| of the linear per-pixel mean <= 5e-4 and >= 97 % of
-    pixels within 2e-3 at <= 16 spp (a pixel is off only when one of its few samples took a
-    different branch: an f32/f64 rounding difference at a rejection test, a Schlick draw or a grazing hit);
+  * same seed, GPU vs f64 oracle: mean |diff| of the linear per-pixel mean <= 3e-5 and >= 99.7 % of
+    pixels within 2e-3 at 8 spp — about 2.5x what MI355X measures (1.2e-5, 0.10-0.12 % of pixels; a pixel is off only when one
+    of its few samples took a different branch: an f32/f64 rounding difference at a rejection test, a Schlick draw or a grazing hit);
   * at 8-bit output: >= 99 % of pixel channels within +-2/255;
   * converged images: relative difference of image means <= 0.5 %.
 """
@@ -37,7 +37,7 @@ def test_book1_same_seed_vs_f64_oracle(pkg, orc, gpu, book1):
     ref, ost = orc.render(hs.desc, cam, prm, precision=64, n_threads=8, count=True)
     mean_abs, frac_bad = compare(img, ref, SPP)
     assert np.isfinite(img).all()
-    assert mean_abs <= 5e-4 and frac_bad <= 0.03, (mean_abs, frac_bad)
+    assert mean_abs <= 3e-5 and frac_bad <= 0.003, (mean_abs, frac_bad)
     a8, b8 = pkg.tonemap(img, SPP).astype(int), pkg.tonemap(ref.astype(np.float32), SPP).astype(int)
     assert np.mean(np.abs(a8 - b8) <= 2) >= 0.99
     # the device walks the same tree in the same order: traversal work agrees to a fraction of a percent
@@ -58,7 +58,7 @@ def test_golden_fixture(pkg, orc, gpu, book1):
     prm = pkg.make_params(64, 40, 8, seed=1)
     img, _ = gpu.render(scene, cam, prm)
     mean_abs, frac_bad = compare(img, g, 8)
-    assert mean_abs <= 5e-4 and frac_bad <= 0.03
+    assert mean_abs <= 3e-5 and frac_bad <= 0.003
 
 
 def test_bit_exact_invariances(pkg, gpu, book1):
@@ -131,7 +131,7 @@ def test_depth_limit(pkg, orc, gpu, book1):
         img, st = gpu.render(scene, cam, prm)
         ref, ost = orc.render(hs.desc, cam, prm, precision=64, n_threads=8, count=True)
         mean_abs, frac_bad = compare(img, ref, 8)
-        assert mean_abs <= 5e-4 and frac_bad <= 0.03
+        assert mean_abs <= 3e-5 and frac_bad <= 0.003
         assert abs(st["segments"] - ost["segments"]) <= max(4, 2e-3 * ost["segments"])
     assert st["segments"] <= 5 * 64 * 40 * 8
 

@@ -1,13 +1,15 @@
 """GPU parity on the other rows of SURVEY §8(a): rects / Box / Translate / RotateY / FlipFace / DiffuseLight /
 MixturePdf (Cornell), ConstantMedium + Isotropic (cornell_smoke, final), MovingSphere + textures (book1_ref,
-final), Triangle. Same seed, GPU (f32) against the f64 oracle; tolerance as in test_gpu_parity.py."""
+final), Triangle. Same seed, GPU (f32) against the f64 oracle. Tolerances (defaults of check()): mean |diff| <= 1.2e-4, pixels off by
+more than 2e-3 <= 1.5 %, segments within 0.2 % — about twice the worst scene measured on MI355X (book1_ref: 4.7e-5, 0.72 %, 1.3e-4;
+book-2 final: segments 1.0e-3); the one outlier scene states its own."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-def check(pkg, orc, gpu, desc, cam, W, H, SPP, mean_tol=5e-4, bad_tol=0.03, seg_tol=5e-3, **kw):
+def check(pkg, orc, gpu, desc, cam, W, H, SPP, mean_tol=1.2e-4, bad_tol=0.015, seg_tol=2e-3, **kw):
     prm = pkg.make_params(W, H, SPP, flags=pkg._abi.RT_FLAG_COUNTERS, **kw)
     img, st = gpu.render(gpu.upload(desc), cam, prm)
     ref, ost = orc.render(desc, cam, prm, precision=64, n_threads=8, count=True)
@@ -98,7 +100,7 @@ def test_instance_wrappers(pkg, orc, gpu, wrap):
            "double_rotate": lambda: b.rotate_y(b.translate(b.rotate_y(inner, 20), (1, 0, 0)), 25)}[wrap]()
     world = b.hittable_list([obj, b.xz_rect(-20, 20, -20, 20, -1.5, g)])
     cam = pkg.camera_new((0, 3, 12), (0, 0, -1), (0, 1, 0), 40, 1.5, 0.0, 10.0, 0, 0)
-    check(pkg, orc, gpu, b.desc(world), cam, 96, 64, 8, bad_tol=0.04)
+    check(pkg, orc, gpu, b.desc(world), cam, 96, 64, 8)
 
 
 def test_bvh_inside_an_instance(pkg, orc, gpu):
@@ -112,7 +114,7 @@ def test_bvh_inside_an_instance(pkg, orc, gpu):
     cam = pkg.camera_new((478, 278, -600), (278, 278, 0), (0, 1, 0), 40, 1.0, 0.0, 10.0, 0, 1)
     # segments within 1.5 %: the f32 round trip through the instance transform still costs a few grazing re-hits of
     # NEIGHBOURING (overlapping) spheres; before the rule the device traced 2.25x the oracle's segments here
-    check(pkg, orc, gpu, b.desc(world), cam, 64, 64, 4, bad_tol=0.02, seg_tol=1.5e-2)
+    check(pkg, orc, gpu, b.desc(world), cam, 64, 64, 4, mean_tol=4e-4, bad_tol=0.02, seg_tol=1.4e-2)   # measured 1.8e-4, 0.93 %, 6.8e-3
 
 
 def test_fog_far_boundary(pkg, orc, gpu):
@@ -121,7 +123,7 @@ def test_fog_far_boundary(pkg, orc, gpu):
     g = b.lambertian((0.48, 0.83, 0.53))
     world = b.hittable_list([b.box((-400, 0, -400), (400, 60, 400), g), b.constant_medium(b.sphere((0, 0, 0), 5000, b.dielectric(1.5)), 0.0001, (1, 1, 1))])
     cam = pkg.camera_new((478, 278, -600), (0, 30, 0), (0, 1, 0), 40, 1.0, 0.0, 10.0, 0, 1)
-    img, ref, st, ost = check(pkg, orc, gpu, b.desc(world), cam, 64, 64, 8, seg_tol=2e-3)
+    img, ref, st, ost = check(pkg, orc, gpu, b.desc(world), cam, 64, 64, 8)
     assert st["segments"] > 1.3 * 64 * 64 * 8     # the fog does scatter
 
 
@@ -193,3 +195,39 @@ def test_imported_obj_mesh(pkg, orc, gpu, tmp_path):
     path.write_text(CUBE_OBJ)
     hs = pkg.HostScene("obj:" + str(path), 1)
     check(pkg, orc, gpu, hs.desc, hs.camera(1.5), 96, 64, 8)
+
+
+def test_time_survives_a_glass_bounce(pkg, orc, gpu):
+    """A ray keeps its time through a Dielectric bounce (material.rs:131-155 builds the scattered ray with r_in.time()) and meets
+    MovingSpheres where they are at THAT time. Regression: the F_ALL instance of k_shade once left the Schlick draw in the time
+    slot, so rays reflected off glass saw moving spheres elsewhere (one wrong sample in a few thousand — inside every statistical
+    tolerance; it was caught by comparing the wavefront kernels with the fused per-path kernel, which shares their code but was
+    compiled right). Checked three ways: against the f64 oracle, wavefront == fused bit for bit, and with time-frozen cameras."""
+    import os
+    A = pkg._abi
+    rng = np.random.default_rng(1)
+    b = pkg.SceneBuilder(background=(0.7, 0.8, 1.0), background_mode=A.RT_BG_SKY_GRADIENT)
+    lam, glass = b.lambertian((0.5, 0.5, 0.5)), b.dielectric(1.5)
+    ids = []
+    for i in range(24):
+        c = np.array([rng.uniform(-2.5, 2.5), 0.3, rng.uniform(-2.5, 2.5)])
+        ids.append(b.moving_sphere(c, c + (0, rng.uniform(0.1, 0.5), 0), 0.0, 1.0, 0.3, lam) if i % 2 else b.sphere(c, 0.3, glass))
+    desc = b.desc(b.bvh(ids, 0.0, 1.0))
+    scene = gpu.upload(desc)
+    old = os.environ.get("RT_DRAIN_AT")
+    try:
+        for t1 in (0.0, 1.0):
+            cam = pkg.camera_new((5, 2, 2), (0, 0.3, 0), (0, 1, 0), 40, 1.5, 0.0, 10.0, 0.0, t1)
+            for depth in (2, 50):
+                os.environ["RT_DRAIN_AT"] = "0"
+                w, sw = gpu.render(scene, cam, pkg.make_params(96, 64, 8, seed=3, max_depth=depth, flags=A.RT_FLAG_COUNTERS))
+                f, sf = gpu.render(scene, cam, pkg.make_params(96, 64, 8, seed=3, max_depth=depth, flags=A.RT_FLAG_COUNTERS | A.RT_FLAG_FUSED))
+                assert np.array_equal(w, f) and sw["node_tests"] == sf["node_tests"] and sw["prim_tests"] == sf["prim_tests"], (t1, depth)
+        os.environ.pop("RT_DRAIN_AT", None)
+        cam = pkg.camera_new((5, 2, 2), (0, 0.3, 0), (0, 1, 0), 40, 1.5, 0.0, 10.0, 0.0, 1.0)
+        check(pkg, orc, gpu, desc, cam, 96, 64, 16)
+    finally:
+        if old is None:
+            os.environ.pop("RT_DRAIN_AT", None)
+        else:
+            os.environ["RT_DRAIN_AT"] = old
