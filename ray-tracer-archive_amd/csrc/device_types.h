@@ -46,6 +46,13 @@ inline uint32_t make_leaf(uint32_t type, uint32_t first, uint32_t count) { retur
 // links lead to itself; its first two words are the address to resume at and the leaf payload); DONE and IDLE are such records too.
 struct NodeDev { float cx, cy, hx, hy, cz, hz; uint32_t skip_bytes, leaf /* = hit link */; };
 static_assert(sizeof(NodeDev) == 32, "device node record is 32 bytes");
+// Compressed record for scenes that do not fit LDS (kernels.hip M_C16; rt_api.cpp device_nodes16): the box corners as u16 on a grid
+// over the scene's bounds (lo rounded down and hi rounded up by one more step than needed, so the decoded box contains the host box
+// plus the decode's rounding), one 16-byte load per visit. link: bit 31 set = a leaf, the low bits its payload (type | count |
+// first; type < 8), its successor is the next record whether the box is passed or not; bit 31 clear = an inner record, link = byte
+// offset of the record to visit when the box is MISSED (passed: the next record). lo.x > hi.x marks a record without a box.
+struct Node16 { uint16_t lo[3], hi[3]; uint32_t link; };
+static_assert(sizeof(Node16) == 16, "compressed node record is 16 bytes");
 // payload words of the two shared self-loop records (leaf type 0 = no primitive work):
 constexpr uint32_t LEAF_IDLE = 1u << 24;   // the lane holds no ray
 constexpr uint32_t LEAF_DONE = 2u << 24;   // the lane's ray has visited every node

@@ -21,6 +21,8 @@ struct SceneDev {
     const rtd::Float4* nodes; uint32_t n_nodes;
     const rtd::Float4* top_nodes; uint32_t n_top;   // top of the tree staged in LDS when the scene does not fit (0: none)
     uint32_t n_records;      // records of `nodes` in all: n_nodes + DONE + IDLE + one park twin per leaf (device_types.h)
+    uint32_t nodes16;        // 1: `nodes` holds 16-byte compressed records (device_types.h Node16), corners on the grid below
+    float grid_lo[3], grid_scale[3];
     uint32_t n_prim_kinds;   // how many of {sphere, moving sphere, rect, triangle, medium} the scene holds
     const rtd::Float4* spheres; const uint32_t* sphere_meta; uint32_t n_spheres;
     const rtd::Float4* moving; const uint32_t* moving_meta;

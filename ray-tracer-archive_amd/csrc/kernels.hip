@@ -468,7 +468,12 @@ constexpr int kLeafBatch = RT_LEAF_BATCH;
 // million paths are alive the wavefront iterations are launch- and latency-bound (41 of 53 iterations moved 1 % of the segments
 // in 7 % of the time), and one kernel that carries each path to its end replaces them. Same functions, same order per path:
 // the frame is bit-identical wherever the hand-over happens.
-enum : int { M_HBM = 0, M_LDS = 1, M_TOP = 2 };
+// M_C16: scenes that do not fit LDS, compressed records (device_types.h Node16: 16 bytes, box corners as u16 on the scene's
+// grid): ONE 16-byte load per visit instead of two and twice the records per cache line — this walk is bound by the vector memory
+// pipe (92 % L2 hits, VALU 8 % busy), so it trades idle VALU (decode: 6 converts + 6 FMAs) for memory instructions. The successor
+// of a passed inner record or of any leaf is the next record; a missed inner record names its skip target. Lane states live in
+// `pend` here (no twins: a twin per leaf would double the array).
+enum : int { M_HBM = 0, M_LDS = 1, M_TOP = 2, M_C16 = 3 };
 struct PathState;
 enum : uint32_t { SH_FINISHED = 1u, SH_TIME_ZERO = 2u };
 template <uint32_t FEAT> DEVI uint32_t shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& d, float tm, PathState& s, Rng& g, uint32_t& depth, uint2 hit, V3& L,
@@ -491,7 +496,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                                                  uint32_t* __restrict__ head, uint32_t* __restrict__ count_out_to_zero,
                                                  unsigned long long* __restrict__ counters, RenderDev rd, uint32_t* __restrict__ next_work) {
     extern __shared__ float4 lds[];
-    constexpr bool LDS = MODE == M_LDS, TOP = MODE == M_TOP;
+    constexpr bool LDS = MODE == M_LDS, TOP = MODE == M_TOP, C16 = MODE == M_C16;
     if (blockIdx.x == 0 && threadIdx.x == 0) *count_out_to_zero = 0u;   // the next k_shade appends to it
     const uint32_t count = *count_ptr;
     const uint32_t lane = threadIdx.x & 63u;
@@ -533,13 +538,31 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     uint32_t w_next = min(wave_id * chunk, count), w_end = min(w_next + chunk, count);
     bool exhausted = false;
 
-    uint32_t slot = 0, node = a_idle, hit_prim = rtd::HIT_NONE, from = 0;
+    uint32_t slot = 0, node = C16 ? 0u : a_idle, hit_prim = rtd::HIT_NONE, from = 0;
     float tmax = kInf, tm = 0.f, a = 1.f;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
     SlabRay sr; sr.inv_xy = sr.noi_xy = sr.ainv_xy = sr.inv_z = sr.noi_z = F2{0.f, 0.f};
     V3 ow = o, dw = d;                 // world ray while inside an instance transform
     uint64_t mkey = 0; uint32_t seg = 0;
     unsigned long long c_nodes = 0, c_prims[RT_N_PRIM_TYPES_K] = {0, 0, 0, 0, 0, 0};
+    uint32_t pend = rtd::LEAF_IDLE;    // M_C16 only: 0 = walking, LEAF_IDLE, LEAF_DONE, or the payload of the leaf the lane waits with
+    // lane states, in either representation (an address on a self-loop record, or the `pend` word)
+    auto is_idle = [&]() { return C16 ? pend == rtd::LEAF_IDLE : node == a_idle; };
+    auto is_done = [&]() { return C16 ? pend == rtd::LEAF_DONE : node == a_done; };
+    auto is_walking = [&]() { return C16 ? pend == 0u : node < special; };
+    auto is_parked = [&]() { return C16 ? (pend >> 28) != 0u : node >= a_twins; };
+    auto go_idle = [&]() { if (C16) pend = rtd::LEAF_IDLE; else node = a_idle; };
+    auto go_root = [&]() { node = 0u; if (C16) pend = 0u; };
+    // per-ray constants of the M_C16 slab test: t = q * qa + qb for a corner coordinate q on the scene's grid
+    V3 qa = v3(0, 0, 0), qb = v3(0, 0, 0);
+    auto set_grid_ray = [&]() {
+        if (C16) {
+            const float kInvMax = 1e18f;
+            const V3 inv = v3(fminf(fmaxf(fast_rcp(d.x), -kInvMax), kInvMax), fminf(fmaxf(fast_rcp(d.y), -kInvMax), kInvMax), fminf(fmaxf(fast_rcp(d.z), -kInvMax), kInvMax));
+            qa = v3(sc.grid_scale[0] * inv.x, sc.grid_scale[1] * inv.y, sc.grid_scale[2] * inv.z);
+            qb = v3((sc.grid_lo[0] - o.x) * inv.x, (sc.grid_lo[1] - o.y) * inv.y, (sc.grid_lo[2] - o.z) * inv.z);
+        }
+    };
 #ifdef RT_DEBUG_LONGWALK
     uint32_t dbg_steps = 0u;
 #endif
@@ -587,7 +610,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     const bool with_acc = rd.block_shift != 0u;
     // a ray the lane has just been given (by the pool or by shading): per-ray constants, walk from the root
     auto begin_walk = [&]() {
-        set_slab_ray(o, d, sr);
+        if (C16) set_grid_ray(); else set_slab_ray(o, d, sr);
         a = len2(d);
         if (FEAT & F_XFORM) { ow = o; dw = d; }
         if (FEAT & F_MEDIUM) {
@@ -595,7 +618,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             seg = depth;
             mkey = path_base(rd.seed, (uint64_t)it.y * rd.width + it.x, sample);
         }
-        from = ps.from; tmax = kInf; hit_prim = rtd::HIT_NONE; node = 0u;
+        from = ps.from; tmax = kInf; hit_prim = rtd::HIT_NONE; go_root();
     };
     if (DRAIN) {
         const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -620,19 +643,19 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         STAMP(st_a);
         // ---- refill: idle lanes take prefetched rays (ballot + prefix rank) ----
         if constexpr (!DRAIN) {
-            const bool is_idle = node == a_idle;
-            const uint64_t idle = __ballot(is_idle);
+            const bool lane_idle = is_idle();
+            const uint64_t idle = __ballot(lane_idle);
             const uint32_t take = min((uint32_t)__popcll(idle), n_cnt);
             if (take != 0u) {
                 const uint32_t rank = lane_rank(idle);
                 const int src = (int)(rank & 63u);
                 const float ox = __shfl(No.x, src), oy = __shfl(No.y, src), oz = __shfl(No.z, src), ot = __shfl(No.w, src);
                 const float dx = __shfl(Nd.x, src), dy = __shfl(Nd.y, src), dz = __shfl(Nd.z, src), dfrom = __shfl(Nd.w, src);
-                if (is_idle && rank < take) {
+                if (lane_idle && rank < take) {
                     slot = w_next + rank;
                     o = v3(ox, oy, oz); d = v3(dx, dy, dz); tm = ot;
                     from = __float_as_uint(dfrom);            // primitive this ray starts on (0: camera / medium)
-                    set_slab_ray(o, d, sr);
+                    if (C16) set_grid_ray(); else set_slab_ray(o, d, sr);
                     a = len2(d);
                     if (FEAT & F_XFORM) { ow = o; dw = d; }
                     if (FEAT & F_MEDIUM) {
@@ -642,7 +665,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                         seg = sd & 0xFFu;
                         mkey = path_base(rd.seed, (uint64_t)it.y * rd.width + it.x, sd >> 8);
                     }
-                    tmax = kInf; node = 0u; hit_prim = rtd::HIT_NONE;   // address 0 = the root (the first record, or its copy in the top)
+                    tmax = kInf; hit_prim = rtd::HIT_NONE; go_root();   // address 0 = the root (the first record, or its copy in the top)
                 }
                 w_next += take;
             }
@@ -664,7 +687,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             const uint32_t idx = n_cnt != 0u ? w_next + min(lane, n_cnt - 1u) : 0u;
             No = pool.ray_o[idx]; Nd = pool.ray_d[idx];
         }
-        if (__ballot(node != a_idle) == 0ull && (DRAIN || n_cnt == 0u)) break;       // queue empty, nothing in flight
+        if (__ballot(!is_idle()) == 0ull && (DRAIN || n_cnt == 0u)) break;       // queue empty, nothing in flight
 #ifdef RT_STAMPS
         STAMP(st_b); st_refill += st_b - st_a;
 #endif
@@ -674,6 +697,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         STAMP(st_b);
 #endif
         // ---- node pass: kSteps visits, every lane, no exec-mask traffic: two 16-byte reads, 5 packed + 8 plain VALU, one select ----
+        if constexpr (!C16) {
 #pragma unroll
         for (int step = 0; step < kSteps; ++step) {
             float4 n0, n1;
@@ -693,8 +717,33 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #endif
             node = tnear <= tfar ? __float_as_uint(n1.w) : __float_as_uint(n1.z);             // hit : skip
         }
+        } else {
+        // M_C16: one 16-byte load; corners decoded from the scene's u16 grid (conservatively rounded by the host), the slab test
+        // with min/max per axis; a lane that is not walking re-reads its own next record and keeps its state
+#pragma unroll
+        for (int step = 0; step < kSteps; ++step) {
+            const bool walk = pend == 0u;
+            const uint4 w = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(nodes) + node);
+            const uint32_t lx = w.x & 0xFFFFu, ly = w.x >> 16, lz = w.y & 0xFFFFu, hx = w.y >> 16, hy = w.z & 0xFFFFu, hz = w.z >> 16;
+            const float t0x = fmaf((float)lx, qa.x, qb.x), t1x = fmaf((float)hx, qa.x, qb.x);
+            const float t0y = fmaf((float)ly, qa.y, qb.y), t1y = fmaf((float)hy, qa.y, qb.y);
+            const float t0z = fmaf((float)lz, qa.z, qb.z), t1z = fmaf((float)hz, qa.z, qb.z);
+            const float tnear = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), kTMin));
+            const float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+            const bool nobox = lx > hx;                                  // the host's mark for a record without a box
+            const bool boxhit = nobox || tnear <= tfar;
+            const bool leaf = (w.w >> 31) != 0u;
+            if (COUNT) c_nodes += (walk && !nobox) ? 1ull : 0ull;
+#ifdef RT_DEBUG_LONGWALK
+            if (COUNT) dbg_steps += walk ? 1u : 0u;
+#endif
+            const uint32_t next = (boxhit || leaf) ? node + 16u : w.w;  // a leaf's subtree is itself: its successor is the next record either way
+            node = walk ? next : node;
+            pend = (walk && boxhit && leaf) ? (w.w & 0x7FFFFFFFu) : pend;
+        }
+        }
         // ---- events, outside the steps: lanes on a self-loop record ----
-        if (!DRAIN && node == a_done) {                                      // walked off the end: world.hit is done
+        if (!DRAIN && is_done()) {                                           // walked off the end: world.hit is done
             pool.hit[slot] = make_uint2(__float_as_uint(tmax), hit_prim);
 #ifdef RT_DEBUG_LONGWALK
             if (COUNT && dbg_steps > 100000u) {
@@ -706,21 +755,23 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             }
             dbg_steps = 0u;
 #endif
-            node = a_idle;
+            go_idle();
         }
         // leaf payload of a parked lane (0 for the others)
-        uint32_t pend = 0u, resume = 0u;
-        const bool parked = node >= a_twins;
-        if (parked) { const uint2 tw = load_twin(node); resume = tw.x; pend = tw.y; }
+        uint32_t pl = 0u, resume = 0u;
+        const bool parked = is_parked();
+        if constexpr (C16) { pl = parked ? pend : 0u; }
+        else { if (parked) { const uint2 tw = load_twin(node); resume = tw.x; pl = tw.y; } }
+        auto move_on = [&]() { if (C16) pend = 0u; else node = resume; };   // past the leaf the lane was parked with
         if (FEAT & F_XFORM) {
-            const uint32_t type = pend >> 28;
+            const uint32_t type = pl >> 28;
             if (type == rtd::LT_ENTER || type == rtd::LT_EXIT) {   // Translate/RotateY::hit: switch ray space, move on
-                const uint32_t xf = pend & rtd::LEAF_MAX_FIRST;
+                const uint32_t xf = pl & rtd::LEAF_MAX_FIRST;
                 if (xf == 0u) { o = ow; d = dw; }
                 else xform_ray(sc.xforms[xf], ow, dw, o, d);
-                set_slab_ray(o, d, sr);
+                if (C16) set_grid_ray(); else set_slab_ray(o, d, sr);
                 if (COUNT) { if (type == rtd::LT_ENTER) c_prims[5]++; }
-                pend = 0u; node = resume;
+                pl = 0u; move_on();
             }
         }
 #ifdef RT_STAMPS
@@ -728,8 +779,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         STAMP(st_a); st_node += st_a - st_b;
 #endif
         // ---- primitive pass: when enough lanes hold a leaf, or nobody can walk any further ----
-        const uint64_t pm = __ballot(pend != 0u);
-        const bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(node < special) == 0ull);
+        const uint64_t pm = __ballot(pl != 0u);
+        const bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(is_walking()) == 0ull);
         // Scenes with four or more primitive kinds (book-2 final: spheres, a moving sphere, rects, media): a pass serves ONE
         // kind, the one most lanes wait with; the others stay parked and win a later pass. Every kind's code then runs with
         // as many lanes as the wave can give it instead of several kinds back to back with a handful of lanes each
@@ -737,7 +788,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         // more than they save (Cornell +2 %, the 1 M-sphere + mesh scene +10 %), hence the scene-level switch.
         uint32_t serve = 0u;   // 0: every kind
         if (FEAT != 0u && sc.n_prim_kinds >= 4u && do_prims) {
-            const uint32_t ty = pend >> 28;
+            const uint32_t ty = pl >> 28;
             uint32_t best = 0u;
 #pragma unroll
             for (uint32_t k = rtd::LT_SPHERE; k <= rtd::LT_MEDIUM; ++k) {
@@ -745,9 +796,9 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                 if (c > best) { best = c; serve = k; }
             }
         }
-        if (do_prims && pend != 0u && (serve == 0u || (pend >> 28) == serve)) {
-            const uint32_t type = pend >> 28, cnt = (pend >> 24) & 15u, first = pend & rtd::LEAF_MAX_FIRST;
-            node = resume;                                        // the record after the leaf, once its primitives are tested
+        if (do_prims && pl != 0u && (serve == 0u || (pl >> 28) == serve)) {
+            const uint32_t type = pl >> 28, cnt = (pl >> 24) & 15u, first = pl & rtd::LEAF_MAX_FIRST;
+            move_on();                                            // the record after the leaf, once its primitives are tested
             if (type == rtd::LT_SPHERE) {
 #ifdef RT_SPHERE_F64_ONLY
                 // two phases, so that the f64 refinement (several times the cost of the filter) runs once per SURVIVOR
@@ -829,10 +880,11 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #endif
         if constexpr (DRAIN) {
             // ---- shading pass: when enough lanes have finished their walk, or nobody can do anything else ----
-            const uint64_t dm = __ballot(node == a_done);
-            if (dm != 0ull && ((int)__popcll(dm) >= kShadeBatch || __ballot(node < special || node >= a_twins) == 0ull)) {
+            const uint64_t dm = __ballot(is_done());
+            if (dm != 0ull && ((int)__popcll(dm) >= kShadeBatch || __ballot(is_walking() || is_parked()) == 0ull)) {
                 bool want = false;
-                if (node == a_done) {
+                const bool lane_done = is_done();
+                if (lane_done) {
                     c_segments++;
                     V3 so = (FEAT & F_XFORM) ? ow : o, sd = (FEAT & F_XFORM) ? dw : d, L;
                     const uint32_t sh = shade_segment<FEAT>(sc, rd, so, sd, tm, ps, g, depth, make_uint2(__float_as_uint(tmax), hit_prim), L, c_light_rect, c_light_sphere);
@@ -855,15 +907,15 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     if (want) {
                         const uint32_t work = base + lane_rank(wm);
                         if (work < rd.total_items) { start_item(rd, work, ps, o, d, tm); g.s = ps.rng; depth = 0; sample = ps.sdepth >> 8; }
-                        else node = a_idle;                                  // nothing left: the lane retires
+                        else go_idle();                                      // nothing left: the lane retires
                     }
                 }
-                if (node == a_done) begin_walk();
+                if (lane_done && !is_idle()) begin_walk();
             }
-            if (__ballot(node != a_idle) == 0ull) break;
+            if (__ballot(!is_idle()) == 0ull) break;
         } else {
         // next refill is due when enough lanes are idle and there is something to hand out, or nobody has a ray
-        const uint64_t hv = __ballot(node != a_idle);
+        const uint64_t hv = __ballot(!is_idle());
         if (hv == 0ull) break;
         if (n_cnt != 0u && 64 - (int)__popcll(hv) >= kRefillMin) break;
         }
@@ -1093,7 +1145,7 @@ DEVI void sphere_uv(V3 p, float& u, float& v) {                                /
 // k_extend so that a path computes the same numbers whichever kernel carries it.
 // The ray's time is an INPUT only: Metal's "scattered ray has time 0.0" (material.rs:101) comes back as the SH_TIME_ZERO flag and the
 // caller applies it. (With `float& tm` assigned in the Metal branch, hipcc 7.2 compiled the F_ALL instance of k_shade so that a
-// Dielectric bounce left the Schlick draw in tm — found as the wavefront frame differing from the drain kernel's and the oracle's on
+// Dielectric bounce left the Schlick draw in tm — found as the wavefront frame differing from the drain kernel's and the CPU restatement's on
 // scenes with glass and moving spheres; tests/test_gpu_scenes.py::test_time_survives_a_glass_bounce keeps watch.)
 template <uint32_t FEAT>
 DEVI uint32_t shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& d, const float tm, PathState& s, Rng& g, uint32_t& depth, uint2 hit, V3& L,
@@ -1434,15 +1486,16 @@ template <int MODE, uint32_t FEAT, bool COUNT>
 static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
     const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
+    constexpr bool kNoLds = MODE == M_HBM || MODE == M_C16;
     // workgroup sizes compiled for this mode: 256 threads always; 512 and 1024 where an LDS copy limits the groups per CU (a
     // 100 KB scene allows ONE group per CU: only a 1024-thread group then keeps 16 waves on it)
-    constexpr uint32_t T0 = kExtendThreads, T1 = MODE == M_HBM ? T0 : 2u * T0, T2 = MODE == M_HBM ? T0 : 4u * T0;
+    constexpr uint32_t T0 = kExtendThreads, T1 = kNoLds ? T0 : 2u * T0, T2 = kNoLds ? T0 : 4u * T0;
     static thread_local size_t cached_lds = ~(size_t)0; static thread_local int nb[3] = {0, 0, 0}; static thread_local int pick = 0;
     if (cached_lds != lds_bytes) {
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[0], k_extend<MODE, FEAT, COUNT, T0, false>, (int)T0, lds_bytes);
         if (e != hipSuccess) return e;
         nb[1] = nb[2] = 0;
-        if (MODE != M_HBM) {
+        if (!kNoLds) {
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[1], k_extend<MODE, FEAT, COUNT, T1, false>, (int)T1, lds_bytes);
             if (e != hipSuccess) return e;
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[2], k_extend<MODE, FEAT, COUNT, T2, false>, (int)T2, lds_bytes);
@@ -1460,8 +1513,8 @@ static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, cons
     }
     if (cfg.extend_geometry) { cfg.extend_geometry[0] = (uint32_t)(pick == 0 ? T0 : pick == 1 ? T1 : T2); cfg.extend_geometry[1] = (uint32_t)nb[pick]; }
     const uint32_t groups = cfg.n_cu * (uint32_t)nb[pick];
-    if (MODE != M_HBM && pick == 2) return launch_extend_g<MODE, FEAT, COUNT, T2>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
-    if (MODE != M_HBM && pick == 1) return launch_extend_g<MODE, FEAT, COUNT, T1>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
+    if (!kNoLds && pick == 2) return launch_extend_g<MODE, FEAT, COUNT, T2>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
+    if (!kNoLds && pick == 1) return launch_extend_g<MODE, FEAT, COUNT, T1>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
     return launch_extend_g<MODE, FEAT, COUNT, T0>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
 }
 template <int MODE, uint32_t FEAT>
@@ -1490,6 +1543,7 @@ hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev
 #define RT_EXT(M, F) launch_extend_t<M, F>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream)
 #define RT_EXT_V(M) (v == 0u ? RT_EXT(M, 0u) : v == kVariantMesh ? RT_EXT(M, kVariantMesh) : v == kVariantBox ? RT_EXT(M, kVariantBox) : RT_EXT(M, F_ALL))
     if (cfg.scene_in_lds) return RT_EXT_V(M_LDS);
+    if (sc.nodes16) return RT_EXT_V(M_C16);
     if (sc.n_top != 0u) return RT_EXT_V(M_TOP);
     return RT_EXT_V(M_HBM);
 #undef RT_EXT_V
@@ -1504,6 +1558,7 @@ hipError_t launch_drain(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev&
                             : launch_drain_c<M, F, false>(sc, pool, rd, max_count, count_ptr, head, cz, next_work, counters, stream))
 #define RT_DRN_V(M) (v == 0u ? RT_DRN(M, 0u) : v == kVariantMesh ? RT_DRN(M, kVariantMesh) : v == kVariantBox ? RT_DRN(M, kVariantBox) : RT_DRN(M, F_ALL))
     if (cfg.scene_in_lds) return RT_DRN_V(M_LDS);
+    if (sc.nodes16) return RT_DRN_V(M_C16);
     if (sc.n_top != 0u) return RT_DRN_V(M_TOP);
     return RT_DRN_V(M_HBM);
 #undef RT_DRN_V

@@ -220,6 +220,45 @@ static bool device_nodes(const std::vector<rtd::Node>& nodes, uint32_t max_top, 
     put((uint32_t)n * 32u + 32u, self_loop(idle, idle, rtd::LEAF_IDLE));
     return true;
 }
+// Compressed layout (device_types.h Node16) for scenes that do not fit LDS. The grid spans the union of the finite boxes; a corner
+// is rounded outwards to the grid and moved one step further out, which covers the decode's rounding (t = q * (scale/d) + (lo - o)/d
+// carries ~1e-7 of the scene's extent in space, a grid step is 1.5e-5 of it). Returns false when the scene has no finite box.
+static bool device_nodes16(const std::vector<rtd::Node>& nodes, std::vector<rtd::Node16>& out, float grid_lo[3], float grid_scale[3]) {
+    const size_t n = nodes.size();
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (const rtd::Node& nd : nodes) for (int a = 0; a < 3; ++a) {
+        if (std::isfinite(nd.mn[a])) lo[a] = std::min(lo[a], (double)nd.mn[a]);
+        if (std::isfinite(nd.mx[a])) hi[a] = std::max(hi[a], (double)nd.mx[a]);
+    }
+    for (int a = 0; a < 3; ++a) {
+        if (!(hi[a] >= lo[a])) return false;
+        const double pad = 1e-6 * (std::fabs(lo[a]) + std::fabs(hi[a])) + 1e-30;
+        lo[a] -= pad; hi[a] += pad;
+        grid_lo[a] = (float)lo[a]; if ((double)grid_lo[a] > lo[a]) grid_lo[a] = std::nextafterf(grid_lo[a], -std::numeric_limits<float>::infinity());
+        double sc = (hi[a] - (double)grid_lo[a]) / 65533.0;               // corners use 1 .. 65534 before the extra step
+        grid_scale[a] = (float)sc; if ((double)grid_scale[a] < sc) grid_scale[a] = std::nextafterf(grid_scale[a], std::numeric_limits<float>::infinity());
+    }
+    if ((uint64_t)(n + 2) * 16ull >= 0x7FFFFFF0ull) return false;          // links are 31-bit byte offsets
+    out.assign(n + 2, rtd::Node16{});
+    for (size_t i = 0; i < n; ++i) {
+        const rtd::Node& nd = nodes[i];
+        rtd::Node16 r{};
+        const bool boxed = std::isfinite(nd.mn[0]) && std::isfinite(nd.mx[0]);
+        if (!boxed) { r.lo[0] = 0xFFFFu; r.hi[0] = 0u; r.lo[1] = r.lo[2] = 0u; r.hi[1] = r.hi[2] = 0xFFFFu; }
+        else for (int a = 0; a < 3; ++a) {
+            const double ql = std::floor(((double)nd.mn[a] - (double)grid_lo[a]) / (double)grid_scale[a]) - 1.0;
+            const double qh = std::ceil(((double)nd.mx[a] - (double)grid_lo[a]) / (double)grid_scale[a]) + 1.0;
+            r.lo[a] = (uint16_t)std::min(65535.0, std::max(0.0, ql));
+            r.hi[a] = (uint16_t)std::min(65535.0, std::max(0.0, qh));
+        }
+        r.link = nd.leaf != 0u ? (0x80000000u | nd.leaf) : (uint32_t)std::min<size_t>(nd.skip, n) * 16u;
+        out[i] = r;
+    }
+    rtd::Node16 end{};                                                      // closing record: no box, "leaf" with the DONE payload (twice: a done lane reads one further)
+    end.lo[0] = 0xFFFFu; end.hi[0] = 0u; end.hi[1] = end.hi[2] = 0xFFFFu; end.link = 0x80000000u | rtd::LEAF_DONE;
+    out[n] = end; out[n + 1] = end;
+    return true;
+}
 static size_t lds_scene_bytes(const rtc::CompiledScene& cs) {
     size_t twins = 0; for (const rtd::Node& nd : cs.nodes) if (nd.leaf != 0u) ++twins;
     return (cs.nodes.size() + 2 + twins) * 32 + cs.spheres.size() * 16;
@@ -242,10 +281,17 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     if (const char* e = getenv("RT_TOP_NODES")) max_top = (uint32_t)std::strtoul(e, nullptr, 10);
     max_top = std::min<uint32_t>(max_top, (128u * 1024u) / 32u);
     DevNodes dn;   // alive until the stream sync below
-    if (!device_nodes(cs.nodes, in_lds ? 0u : max_top, dn)) { delete s; return set_err(ctx, RT_ERR_UNSUPPORTED, "scene: node array beyond 4 GB"); }
-    const bool top = dn.n_top != 0u;
+    std::vector<rtd::Node16> n16;
+    float grid_lo[3] = {0, 0, 0}, grid_scale[3] = {1, 1, 1};
+    // RT_NODE16=0: keep 32-byte records (with the top of the tree in LDS) for a scene that does not fit LDS; default: 16-byte records
+    bool want16 = !in_lds;
+    if (const char* e = getenv("RT_NODE16")) want16 = want16 && e[0] != '0';
+    const bool c16 = want16 && device_nodes16(cs.nodes, n16, grid_lo, grid_scale);
+    if (!c16 && !device_nodes(cs.nodes, in_lds ? 0u : max_top, dn)) { delete s; return set_err(ctx, RT_ERR_UNSUPPORTED, "scene: node array beyond 4 GB"); }
+    const bool top = !c16 && dn.n_top != 0u;
     if (top) up(s->top_nodes, dn.top);
-    up(s->nodes, dn.main); up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
+    if (c16) up(s->nodes, n16); else up(s->nodes, dn.main);
+    up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
     up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->media, cs.media);
     up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
     up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
@@ -253,7 +299,8 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     if (r != RT_OK) { rt_scene_destroy(ctx, s); return r; }
     rtk::SceneDev& d = s->dev;
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
-    d.top_nodes = top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = dn.n_top; d.n_records = dn.records();
+    d.top_nodes = top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = top ? dn.n_top : 0u; d.n_records = c16 ? (uint32_t)n16.size() : dn.records();
+    d.nodes16 = c16 ? 1u : 0u; for (int a = 0; a < 3; ++a) { d.grid_lo[a] = grid_lo[a]; d.grid_scale[a] = grid_scale[a]; }
     d.n_prim_kinds = (cs.sphere_meta.empty() ? 0u : 1u) + (cs.moving_meta.empty() ? 0u : 1u) + (cs.rect_meta.empty() ? 0u : 1u) +
                      (cs.tri_meta.empty() ? 0u : 1u) + (cs.media.empty() ? 0u : 1u);
     d.spheres = (const rtd::Float4*)s->spheres.p; d.sphere_meta = (const uint32_t*)s->sphere_meta.p; d.n_spheres = (uint32_t)cs.spheres.size();
