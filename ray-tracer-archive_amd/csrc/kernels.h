@@ -86,6 +86,7 @@ struct LaunchCfg {
     uint32_t* extend_geometry;   // optional out: resident workgroups per CU for 256- and 512-thread groups
     uint32_t features;        // F_* the scene needs
     bool scene_in_lds;
+    uint32_t max_rays;        // upper bound of the rays in the queue of this launch of k_extend (sizes its grid when the queue is short)
 };
 
 hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_init, uint32_t* next_work, uint32_t* out_count, hipStream_t stream);

@@ -430,7 +430,7 @@ DEVI void set_slab_ray(V3 o, V3 d, SlabRay& r) {
 #define RT_CHUNK 1024       // rays a wave takes from the queue head per atomic (2^28 rays per launch: same-address atomics cost ~11 ns each)
 #endif
 #ifndef RT_STEPS
-#define RT_STEPS 4          // node visits between two looks at the leaf batch / the refill
+#define RT_STEPS 3          // node visits between two looks at the leaf batch / the refill (measured: 2: 63.9 ms, 3: 59.7, 4: 60.9, 6: 60.8, 8: 65.4)
 #endif
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 24    // lanes with a pending leaf that trigger a primitive-test pass
@@ -995,7 +995,10 @@ DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const P
 // consecutive indices from *counter (ONE returning atomic per workgroup: same-address atomics
 // serialise at the L2, so per-wave atomics would bound the kernel). wave64 ballot + prefix inside a
 // wave, a tiny LDS scan across waves.
-constexpr uint32_t kShadeThreads = 512;
+#ifndef RT_SHADE_THREADS
+#define RT_SHADE_THREADS 512
+#endif
+constexpr uint32_t kShadeThreads = RT_SHADE_THREADS;
 DEVI uint32_t block_alloc(bool flag, uint32_t* counter, uint32_t* s_scan) {
     const uint32_t wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint64_t m = __ballot(flag);
@@ -1512,7 +1515,10 @@ static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, cons
         cached_lds = lds_bytes;
     }
     if (cfg.extend_geometry) { cfg.extend_geometry[0] = (uint32_t)(pick == 0 ? T0 : pick == 1 ? T1 : T2); cfg.extend_geometry[1] = (uint32_t)nb[pick]; }
-    const uint32_t groups = cfg.n_cu * (uint32_t)nb[pick];
+    // the resident set, or fewer workgroups when the queue is short (the host's upper bound of it): a wave needs 64 rays to be worth
+    // starting, and every workgroup started stages the scene and reads the queue size — the floor of the launches of a render's tail
+    const uint32_t tpb = pick == 0 ? T0 : pick == 1 ? T1 : T2;
+    const uint32_t groups = std::min<uint32_t>(cfg.n_cu * (uint32_t)nb[pick], std::max<uint32_t>(1u, (cfg.max_rays + tpb - 1u) / tpb));
     if (!kNoLds && pick == 2) return launch_extend_g<MODE, FEAT, COUNT, T2>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
     if (!kNoLds && pick == 1) return launch_extend_g<MODE, FEAT, COUNT, T1>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
     return launch_extend_g<MODE, FEAT, COUNT, T0>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
@@ -1539,6 +1545,7 @@ static uint32_t pick_variant(uint32_t need) {
 
 hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                          uint32_t* head, uint32_t* cz, unsigned long long* counters, bool count, hipStream_t stream) {
+    if (cfg.max_rays == 0u) return hipSuccess;
     const uint32_t v = pick_variant(cfg.features);
 #define RT_EXT(M, F) launch_extend_t<M, F>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream)
 #define RT_EXT_V(M) (v == 0u ? RT_EXT(M, 0u) : v == kVariantMesh ? RT_EXT(M, kVariantMesh) : v == kVariantBox ? RT_EXT(M, kVariantBox) : RT_EXT(M, F_ALL))

@@ -492,6 +492,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         }
         hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
         if (timing) HIP_TRY(ctx, next_event(ea));
+        cfg.max_rays = live;
         HIP_TRY(ctx, rtk::launch_extend(cfg, scene->dev, pd[cur], rd, c_count[cur], c_head, c_count[1 - cur], c64, counting, ctx->stream));
         if (timing) HIP_TRY(ctx, next_event(eb));
         HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, c_count[cur], c_count[1 - cur], c_next_work, c_head, c64, counting,

@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {
     "base": [],
+    "sh1024": ["RT_SHADE_THREADS=1024"],
+    "sh256": ["RT_SHADE_THREADS=256"],
     "dbgwork": ["RT_DEBUG_WORK=3000u"],
     "b1r1s1": ["RT_LEAF_BATCH=1", "RT_REFILL_MIN=1", "RT_STEPS=1"],
     "b64": ["RT_LEAF_BATCH=64"],

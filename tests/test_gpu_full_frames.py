@@ -30,7 +30,8 @@ TOL = {
     # tiny linear differences into 8-bit steps; the r = 5000 fog sphere makes the scene extent (hence the box padding) large
     "C3": dict(mean=1.5e-4, bad=0.027, bit8=0.93, seg=5e-3, node=0.10, prim=0.27),     # measured 7.3e-5, 0.014, 0.965, 2.4e-3, 4.9e-2, 0.13
     "C4": dict(mean=2.6e-4, bad=0.014, bit8=0.997, seg=2e-5, node=1e-9, prim=2e-5),    # measured 1.3e-4, 6.8e-3, 0.9987, 7e-6, 0 (no BVH), 8e-6
-    "C5": dict(mean=4e-4, bad=0.025, bit8=0.99, seg=7e-4, node=1e-2, prim=1.5e-2),     # measured 2.0e-4, 0.012, 0.996, 3.4e-4, 3.4e-3, 5.5e-3
+    # C5 walks 16-byte compressed records (corners on a u16 grid over the scene): boxes a grid step looser, so more tests — culling only
+    "C5": dict(mean=4e-4, bad=0.025, bit8=0.99, seg=7e-4, node=0.05, prim=0.16),       # measured 2.0e-4, 0.012, 0.996, 3.4e-4, 2.4e-2, 8.1e-2
 }
 METRICS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_metrics.jsonl")
 
