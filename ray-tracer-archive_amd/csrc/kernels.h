@@ -43,6 +43,10 @@ struct SceneDev {
 //   s0 = (T.rgb, work item)      s3 = (rng counter lo, hi, sample << 8 | depth)          s1 = (acc.rgb, -)  multi-sample items only
 // 60 bytes per path (+ 8 for the hit): T = throughput of the sample in flight, acc = sum over the finished samples of the current work
 // item. The radiance of the sample in flight needs no slot (kernels.hip PathState); the pixel is decoded from the work item.
+// The pool is kQueues independent queues of queue_cap slots each (slot s of queue q = record q * queue_cap + s): paths stay in
+// their queue for life, every counter (pool size, queue head, next work item) exists once per queue, kQStride u32 = 128 bytes apart.
+// One counter pair for the whole pool made k_shade wait on same-address atomics (one per 512 paths, ~11 ns each: 29 ms of 39).
+constexpr uint32_t kQueues = 8, kQStride = 32;
 struct U3 { uint32_t x, y, z; };
 struct PoolDev {
     rtd::Float4* ray_o; rtd::Float4* ray_d; uint2* hit;
@@ -74,6 +78,8 @@ struct RenderDev {
     uint32_t block_shift;   // a work item covers 1 << block_shift consecutive samples of one pixel
     uint32_t n_blocks;      // work items per pixel = ceil(spp >> block_shift)
     uint32_t total_items;   // in-image pixels of this shard * n_blocks
+    uint32_t n_init;        // work items 0 .. n_init-1 are the pool's first fill; later ones are dealt to the queues (kernels.hip queue_item)
+    uint32_t queue_cap;     // slots per queue
     uint32_t n_local_tiles;
     const uint32_t* tile_prefix;  // [n_local_tiles + 1]: in-image pixels in local tiles before lt
     uint32_t tile_slack;          // the tile of pixel q is within [q / ts^2, q / ts^2 + tile_slack] (edge tiles are clipped)

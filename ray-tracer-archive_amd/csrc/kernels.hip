@@ -406,6 +406,14 @@ DEVI WorkItem decode_work(const RenderDev& rd, uint32_t w) {
     return it;
 }
 
+// Work items beyond the pool's first fill (items 0 .. n_init-1) are dealt to the queues in runs of 64: queue q's t-th draw is item
+// n_init + ((t / 64) * kQueues + q) * 64 + t % 64 (so 64 consecutive draws of a queue still cover one 8x8 pixel square); valid while
+// below total_items. Which queue renders an item does not matter to the picture (per-item sums, RNG keyed by pixel and sample).
+DEVI uint32_t queue_item(const RenderDev& rd, uint32_t q, uint32_t t) {
+    const uint64_t item = (uint64_t)rd.n_init + ((uint64_t)(t >> 6) * kQueues + q) * 64u + (t & 63u);
+    return item < (uint64_t)rd.total_items ? (uint32_t)item : 0xFFFFFFFFu;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_extend — world.hit for the whole pool
 // ------------------------------------------------------------------------------------------------
@@ -497,10 +505,16 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                                                  unsigned long long* __restrict__ counters, RenderDev rd, uint32_t* __restrict__ next_work) {
     extern __shared__ float4 lds[];
     constexpr bool LDS = MODE == M_LDS, TOP = MODE == M_TOP, C16 = MODE == M_C16;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out_to_zero = 0u;   // the next k_shade appends to it
-    const uint32_t count = *count_ptr;
+    // The pool is kQueues independent queues (kernels.h): a wave serves the queue of its number mod kQueues, a DRAIN workgroup the
+    // queue of its block number; every counter exists once per queue, 128 bytes apart.
+    if (blockIdx.x == 0 && threadIdx.x < kQueues) count_out_to_zero[threadIdx.x * kQStride] = 0u;   // the next k_shade appends to them
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave_all = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t q = DRAIN ? (blockIdx.x & (kQueues - 1u)) : (wave_all & (kQueues - 1u));
+    const uint32_t qbase = q * rd.queue_cap;
+    const uint32_t count = count_ptr[q * kQStride];
+    head += q * kQStride;
+    const uint32_t n_waves = max(1u, (gridDim.x * (blockDim.x >> 6)) / kQueues);   // waves serving this queue (the host launches a multiple of kQueues waves)
     uint32_t chunk = count > kChunk * n_waves ? kChunk : max(64u, (count / (2u * n_waves)) & ~63u);
     // the first chunk of every wave is static (wave w owns [w*chunk, (w+1)*chunk)); the queue head counts from
     // behind them. Otherwise every wave of the grid would hit the head with a returning atomic in the same
@@ -508,8 +522,9 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     const uint32_t head0 = n_waves * chunk;         // the dynamic part of the queue starts behind the static chunks
     // Short queue (the long tail of a render, hundreds of launches with a few thousand rays): a workgroup whose
     // waves own no static chunk has no dynamic chunk to fetch either — leave before staging the scene.
-    if (!DRAIN && blockIdx.x * (blockDim.x >> 6) * chunk >= count && head0 >= count) return;
-    if (DRAIN && blockIdx.x * blockDim.x >= count) return;                  // lane i carries path i
+    const uint32_t wave_id = wave_all / kQueues;     // this wave's number among the waves of its queue
+    if (!DRAIN && __syncthreads_or((wave_id * chunk < count || head0 < count) ? 1 : 0) == 0) return;   // no wave of this workgroup has anything to do
+    if (DRAIN && (blockIdx.x / kQueues) * blockDim.x >= count) return;      // lane i of the queue's workgroups carries path i
     const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
     const float4* spheres = reinterpret_cast<const float4*>(sc.spheres);
     const uint32_t top_bytes = TOP ? sc.n_top * 32u : 0u;
@@ -534,7 +549,6 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     }
     // the three kinds of self-loop records, by address (device_nodes): DONE, IDLE, then the park twins
     const uint32_t special = top_bytes + sc.n_nodes * 32u, a_done = special, a_idle = special + 32u, a_twins = special + 64u;
-    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     uint32_t w_next = min(wave_id * chunk, count), w_end = min(w_next + chunk, count);
     bool exhausted = false;
 
@@ -621,13 +635,13 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         from = ps.from; tmax = kInf; hit_prim = rtd::HIT_NONE; go_root();
     };
     if (DRAIN) {
-        const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+        const uint32_t i = (blockIdx.x / kQueues) * blockDim.x + threadIdx.x;
         if (i < count) {
-            const Float4 ro = pool.ray_o[i], rdv = pool.ray_d[i], s0 = pool.s0[i];
-            const U3 s3 = pool.s3[i];
+            const Float4 ro = pool.ray_o[qbase + i], rdv = pool.ray_d[qbase + i], s0 = pool.s0[qbase + i];
+            const U3 s3 = pool.s3[qbase + i];
             o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
             ps.T = v3(s0.x, s0.y, s0.z); ps.work = __float_as_uint(s0.w); ps.sdepth = s3.z; ps.from = __float_as_uint(rdv.w);
-            if (with_acc) { const Float4 s1 = pool.s1[i]; ps.acc = v3(s1.x, s1.y, s1.z); }
+            if (with_acc) { const Float4 s1 = pool.s1[qbase + i]; ps.acc = v3(s1.x, s1.y, s1.z); }
             g.s = (uint64_t)s3.x | ((uint64_t)s3.y << 32);
             depth = ps.sdepth & 0xFFu; sample = ps.sdepth >> 8;
             begin_walk();
@@ -660,8 +674,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     if (FEAT & F_XFORM) { ow = o; dw = d; }
                     if (FEAT & F_MEDIUM) {
                         // the free-path draws are keyed by the path's RNG base: pixel from the work item, sample from the state word
-                        const uint32_t sd = pool.s3[slot].z;
-                        const WorkItem it = decode_work(rd, __float_as_uint(pool.s0[slot].w));
+                        const uint32_t sd = pool.s3[qbase + slot].z;
+                        const WorkItem it = decode_work(rd, __float_as_uint(pool.s0[qbase + slot].w));
                         seg = sd & 0xFFu;
                         mkey = path_base(rd.seed, (uint64_t)it.y * rd.width + it.x, sd >> 8);
                     }
@@ -684,7 +698,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             }
             // prefetch for the next refill: every lane loads (index clamped, slot 0 when nothing is left)
             n_cnt = exhausted ? 0u : min(64u, w_end - w_next);
-            const uint32_t idx = n_cnt != 0u ? w_next + min(lane, n_cnt - 1u) : 0u;
+            const uint32_t idx = qbase + (n_cnt != 0u ? w_next + min(lane, n_cnt - 1u) : 0u);
             No = pool.ray_o[idx]; Nd = pool.ray_d[idx];
         }
         if (__ballot(!is_idle()) == 0ull && (DRAIN || n_cnt == 0u)) break;       // queue empty, nothing in flight
@@ -744,7 +758,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         }
         // ---- events, outside the steps: lanes on a self-loop record ----
         if (!DRAIN && is_done()) {                                           // walked off the end: world.hit is done
-            pool.hit[slot] = make_uint2(__float_as_uint(tmax), hit_prim);
+            pool.hit[qbase + slot] = make_uint2(__float_as_uint(tmax), hit_prim);
 #ifdef RT_DEBUG_LONGWALK
             if (COUNT && dbg_steps > 100000u) {
                 atomicAdd(&counters[CTR_DEBUG + 0], 1ull);
@@ -902,10 +916,10 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                 const uint64_t wm = __ballot(want);
                 if (wm != 0ull) {
                     uint32_t base = 0;
-                    if (lane == (uint32_t)__builtin_ctzll(wm)) base = atomicAdd(next_work, (uint32_t)__popcll(wm));
+                    if (lane == (uint32_t)__builtin_ctzll(wm)) base = atomicAdd(next_work + q * kQStride, (uint32_t)__popcll(wm));
                     base = (uint32_t)__shfl((int)base, __builtin_ctzll(wm));
                     if (want) {
-                        const uint32_t work = base + lane_rank(wm);
+                        const uint32_t work = queue_item(rd, q, base + lane_rank(wm));
                         if (work < rd.total_items) { start_item(rd, work, ps, o, d, tm); g.s = ps.rng; depth = 0; sample = ps.sdepth >> 8; }
                         else go_idle();                                      // nothing left: the lane retires
                     }
@@ -1024,15 +1038,20 @@ DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, V3& o, V3
 }
 
 __global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, RenderDev rd, uint32_t n_init, uint32_t* __restrict__ next_work, uint32_t* __restrict__ out_count) {
-    // the first fill of the pool needs no allocator: slot i takes work item i (the host passes n_init <= total_items), and the two
-    // counters get their values from one thread. (The atomics + barriers of block_alloc made this kernel latency-bound: 6.0 ms for
-    // 268 M paths at 41 % of the HBM write rate.)
+    // the first fill of the pool needs no allocator: work item i goes to queue (i / 512) mod kQueues, slot (i / 4096) * 512 + i mod 512
+    // of it (the host passes n_init <= total_items), and the counters get their values from kQueues threads. (With the atomics +
+    // barriers of block_alloc this kernel was latency-bound: 6.0 ms for 268 M paths at 41 % of the HBM write rate.)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0u) { *next_work = n_init; *out_count = n_init; }
+    if (i < kQueues) {
+        const uint32_t full = (n_init / (512u * kQueues)) * 512u, rem = n_init % (512u * kQueues);
+        out_count[i * kQStride] = full + min(512u, rem > i * 512u ? rem - i * 512u : 0u);
+        next_work[i * kQStride] = 0u;
+    }
     if (i < n_init) {
         PathState s; V3 o, d; float tm;
         start_item(rd, i, s, o, d, tm);
-        store_path(pool, i, o, d, tm, s, rd.block_shift != 0u);
+        const uint32_t q = (i >> 9) & (kQueues - 1u), slot = ((i / (512u * kQueues)) << 9) | (i & 511u);
+        store_path(pool, q * rd.queue_cap + slot, o, d, tm, s, rd.block_shift != 0u);
     }
 }
 
@@ -1352,12 +1371,20 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
                                                 uint32_t* __restrict__ count_out, uint32_t* __restrict__ next_work, uint32_t* __restrict__ head_to_zero,
                                                 unsigned long long* __restrict__ counters) {
     __shared__ uint32_t s_scan[kShadeThreads / 64 + 1];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t count_in = *count_in_ptr;
+    // workgroup b shades 512 paths of queue b mod kQueues and compacts the survivors into the same queue of the other pool: one
+    // counter pair per queue, so the same-address atomics of all the workgroups (one per 512 paths, ~11 ns each at the memory side:
+    // 29 ms of a 39 ms kernel with ONE pair) spread over kQueues addresses
+    const uint32_t q = blockIdx.x & (kQueues - 1u), i = (blockIdx.x / kQueues) * blockDim.x + threadIdx.x, qbase = q * rd.queue_cap;
+    const uint32_t count_in = count_in_ptr[q * kQStride];
+    count_out += q * kQStride; next_work += q * kQStride;
     if (i == 0u) {
-        *head_to_zero = 0u;                                                   // queue head of the next k_extend
+        head_to_zero[q * kQStride] = 0u;                                      // queue head of the next k_extend
         atomicAdd(&counters[CTR_SEGMENTS], (unsigned long long)count_in);     // world.hit calls so far
-        if (count_in) atomicAdd(&counters[CTR_ITERATIONS], 1ull);
+        if (q == 0u) {
+            uint32_t any = 0u;
+            for (uint32_t k = 0; k < kQueues; ++k) any |= count_in_ptr[k * kQStride];
+            if (any) atomicAdd(&counters[CTR_ITERATIONS], 1ull);
+        }
     }
     bool alive = i < count_in;
     const bool with_acc = rd.block_shift != 0u;
@@ -1365,11 +1392,11 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     unsigned long long c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
     bool want_work = false;
     if (alive) {
-        const Float4 ro = in.ray_o[i], rdv = in.ray_d[i], s0 = in.s0[i];
-        const U3 s3 = in.s3[i]; const uint2 hit = in.hit[i];
+        const Float4 ro = in.ray_o[qbase + i], rdv = in.ray_d[qbase + i], s0 = in.s0[qbase + i];
+        const U3 s3 = in.s3[qbase + i]; const uint2 hit = in.hit[qbase + i];
         o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
         s.T = v3(s0.x, s0.y, s0.z); s.work = __float_as_uint(s0.w); s.sdepth = s3.z;
-        if (with_acc) { const Float4 s1 = in.s1[i]; s.acc = v3(s1.x, s1.y, s1.z); }   // else 0: the item is this one sample
+        if (with_acc) { const Float4 s1 = in.s1[qbase + i]; s.acc = v3(s1.x, s1.y, s1.z); }   // else 0: the item is this one sample
         V3 L = v3(0.f, 0.f, 0.f);          // radiance of this sample: set by the terminal event only
         s.rng = (uint64_t)s3.x | ((uint64_t)s3.y << 32);
         Rng g; g.s = s.rng;
@@ -1392,8 +1419,9 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
 
     // ---- regeneration: a slot whose block is complete draws a new work item (one atomic per workgroup) ----
     {
-        const uint32_t work = block_alloc(want_work, next_work, s_scan);
+        const uint32_t t = block_alloc(want_work, next_work, s_scan);
         if (want_work) {
+            const uint32_t work = queue_item(rd, q, t);
             if (work < rd.total_items) start_item(rd, work, s, o, d, tm);
             else alive = false;
         }
@@ -1402,7 +1430,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     // ---- compaction: survivors go to the other pool densely (wave64 ballot + prefix, LDS scan across waves) ----
     {
         const uint32_t dst = block_alloc(alive, count_out, s_scan);
-        if (alive) store_path(out, dst, o, d, tm, s, with_acc);
+        if (alive) store_path(out, qbase + dst, o, d, tm, s, with_acc);
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { c_samples += __shfl_down(c_samples, off); c_light_rect += __shfl_down(c_light_rect, off); c_light_sphere += __shfl_down(c_light_sphere, off); }
@@ -1482,7 +1510,8 @@ static hipError_t launch_drain_c(const SceneDev& sc, const PoolDev& pool, const 
                                  uint32_t* next_work, unsigned long long* counters, hipStream_t stream) {
     const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
     constexpr uint32_t T = kExtendThreads;
-    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, T, true>), dim3((max_count + T - 1u) / T), dim3(T), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd, next_work);
+    // max_count = upper bound of the paths in ONE queue
+    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, T, true>), dim3(kQueues * ((max_count + T - 1u) / T)), dim3(T), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd, next_work);
     return hipGetLastError();
 }
 template <int MODE, uint32_t FEAT, bool COUNT>
@@ -1518,7 +1547,9 @@ static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, cons
     // the resident set, or fewer workgroups when the queue is short (the host's upper bound of it): a wave needs 64 rays to be worth
     // starting, and every workgroup started stages the scene and reads the queue size — the floor of the launches of a render's tail
     const uint32_t tpb = pick == 0 ? T0 : pick == 1 ? T1 : T2;
-    const uint32_t groups = std::min<uint32_t>(cfg.n_cu * (uint32_t)nb[pick], std::max<uint32_t>(1u, (cfg.max_rays + tpb - 1u) / tpb));
+    uint32_t groups = std::min<uint32_t>(cfg.n_cu * (uint32_t)nb[pick], std::max<uint32_t>(1u, (cfg.max_rays + tpb - 1u) / tpb));
+    const uint32_t gq = std::max<uint32_t>(1u, kQueues * 64u / tpb);     // workgroups that make up kQueues waves: every queue gets the same number of waves
+    groups = (groups + gq - 1u) / gq * gq;
     if (!kNoLds && pick == 2) return launch_extend_g<MODE, FEAT, COUNT, T2>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
     if (!kNoLds && pick == 1) return launch_extend_g<MODE, FEAT, COUNT, T1>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
     return launch_extend_g<MODE, FEAT, COUNT, T0>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
@@ -1583,7 +1614,7 @@ static void launch_shade_t(uint32_t blocks, const SceneDev& sc, const PoolDev& i
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
                         const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, uint32_t* hz, unsigned long long* counters, bool count,
                         hipStream_t stream) {
-    const uint32_t blocks = (max_count + kShadeThreads - 1u) / kShadeThreads;
+    const uint32_t blocks = kQueues * ((max_count + kShadeThreads - 1u) / kShadeThreads);   // max_count = upper bound of the paths in ONE queue
     if (blocks == 0u) return hipSuccess;
     const uint32_t v = pick_variant(cfg.features);
     if (v == 0u) launch_shade_t<0u>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);

@@ -87,7 +87,7 @@ static int ctx_init(RtCtx* ctx, void* stream) {
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
     if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else { HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
-    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_count, 64, hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_count, 8 * rtk::kQueues * sizeof(uint32_t), hipHostMallocDefault));   // ring of 8 x (one pool size per queue)
     HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_counters, sizeof(unsigned long long) * 16, hipHostMallocDefault));
     return RT_OK;
 }
@@ -410,7 +410,10 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
             while (P > (1u << 20) && (size_t)P * slot_bytes > budget) P >>= 1;
         }
     }
-    P = std::max<uint32_t>(256u, (P + 255u) & ~255u);
+    // kQueues queues of queue_cap slots, filled 512 at a time in turn (k_generate): P is a multiple of 512 * kQueues
+    constexpr uint32_t kGrain = 512u * rtk::kQueues;
+    P = std::max<uint32_t>(kGrain, (uint32_t)std::min<uint64_t>(((uint64_t)P + kGrain - 1u) / kGrain * kGrain, 0xFFFFF000ull));
+    rd.queue_cap = P / rtk::kQueues;
     rtk::PoolDev pd[2];
     for (int k = 0; k < 2; ++k) {
         for (int a = 0; a < 6; ++a) if (rec[a]) HIP_TRY(ctx, ctx->pool[k][a].ensure((size_t)P * rec[a]));
@@ -427,14 +430,16 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     rd.tile_prefix = (const uint32_t*)ctx->tile_prefix.p;
     // counters, one 128-byte line each (they are hit by atomics from every workgroup):
     // line 0 next_work, line 1 queue head, lines 2,3 pool counts; 64-bit statistics from line 4
-    constexpr size_t kLine = 128;
-    HIP_TRY(ctx, ctx->counters.ensure(4 * kLine + sizeof(unsigned long long) * 16));
+    // (four counters per queue: next work item, queue head, size of either pool; each on a line of its own)
+    constexpr size_t kLine = 128, kQ = rtk::kQueues;
+    static_assert(rtk::kQStride * sizeof(uint32_t) == kLine, "queue counters are one line apart");
+    HIP_TRY(ctx, ctx->counters.ensure(4 * kQ * kLine + sizeof(unsigned long long) * 16));
     char* cbase = (char*)ctx->counters.p;
-    uint32_t* c_next_work = (uint32_t*)(cbase + 0 * kLine);
-    uint32_t* c_head = (uint32_t*)(cbase + 1 * kLine);
-    uint32_t* c_count[2] = {(uint32_t*)(cbase + 2 * kLine), (uint32_t*)(cbase + 3 * kLine)};
-    unsigned long long* c64 = (unsigned long long*)(cbase + 4 * kLine);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, 4 * kLine + sizeof(unsigned long long) * 16, ctx->stream));
+    uint32_t* c_next_work = (uint32_t*)(cbase + 0 * kQ * kLine);
+    uint32_t* c_head = (uint32_t*)(cbase + 1 * kQ * kLine);
+    uint32_t* c_count[2] = {(uint32_t*)(cbase + 2 * kQ * kLine), (uint32_t*)(cbase + 3 * kQ * kLine)};
+    unsigned long long* c64 = (unsigned long long*)(cbase + 4 * kQ * kLine);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, 4 * kQ * kLine + sizeof(unsigned long long) * 16, ctx->stream));
 
     const bool counting = (prm->flags & RT_FLAG_COUNTERS) != 0, timing = (prm->flags & RT_FLAG_TIMING) != 0;
     rtk::LaunchCfg cfg{};
@@ -453,9 +458,11 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) HIP_TRY(ctx, next_event(e0));
     const uint32_t n_init = (uint32_t)std::min<uint64_t>(P, total_items);
+    rd.n_init = n_init;
     HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, n_init, c_next_work, c_count[0], ctx->stream));
     if (timing) { HIP_TRY(ctx, next_event(e1)); spans.push_back({e0, e1, 2}); }
-    uint32_t live = n_init;   // upper bound of the pool's size from here on: it never grows
+    // upper bound of the size of the LARGEST queue from here on (a queue never grows): it sizes the grids, and 0 ends the render
+    uint32_t live = std::min<uint32_t>(rd.queue_cap, (n_init + rtk::kQueues - 1u) / rtk::kQueues + 512u);
     int cur = 0;
     // The host never waits for an iteration it has just enqueued: the kernels read the pool size from device memory and size-check
     // themselves, so the host only needs (a) an UPPER BOUND of the pool size to size k_shade's grid and (b) to learn that it has
@@ -467,7 +474,10 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     struct Pending { hipEvent_t ev; uint32_t ring; };
     std::vector<Pending> pending;      // oldest first
     size_t pending_head = 0;
-    auto take = [&](const Pending& pd_) { live = std::min(live, ctx->h_count[pd_.ring]); };
+    auto take = [&](const Pending& pd_) {
+        uint32_t m = 0; for (uint32_t k = 0; k < rtk::kQueues; ++k) m = std::max(m, ctx->h_count[pd_.ring * rtk::kQueues + k]);
+        live = std::min(live, m);
+    };
     // The tail goes to the drain kernel: once at most `drain_at` paths are alive, ONE launch carries each of them to its end
     // (kernels.hip DRAIN). RT_FLAG_FUSED hands the whole render to it (a diagnostic: bit-identical frame, slower).
     uint32_t drain_at = 1u << 18;   // measured on the bench workload: hand-over at 2^18 paths 103.2 ms, never 104.1, at 2^21 106.5, at 2^24 121
@@ -482,17 +492,17 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
             take(pending[pending_head++]);
             if (live == 0) break;
         }
-        if (live <= drain_at) {
+        if ((uint64_t)live * rtk::kQueues <= drain_at) {
             hipEvent_t ea = nullptr, eb = nullptr;
             if (timing) HIP_TRY(ctx, next_event(ea));
             HIP_TRY(ctx, rtk::launch_drain(cfg, scene->dev, pd[cur], rd, live, c_count[cur], c_head, c_count[1 - cur], c_next_work, c64, counting, ctx->stream));
             if (timing) { HIP_TRY(ctx, next_event(eb)); spans.push_back({ea, eb, 3}); }
-            drained = live;
+            drained = live * rtk::kQueues;
             break;
         }
         hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
         if (timing) HIP_TRY(ctx, next_event(ea));
-        cfg.max_rays = live;
+        cfg.max_rays = (uint32_t)std::min<uint64_t>((uint64_t)live * rtk::kQueues, 0xFFFFFFFFull);
         HIP_TRY(ctx, rtk::launch_extend(cfg, scene->dev, pd[cur], rd, c_count[cur], c_head, c_count[1 - cur], c64, counting, ctx->stream));
         if (timing) HIP_TRY(ctx, next_event(eb));
         HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, c_count[cur], c_count[1 - cur], c_next_work, c_head, c64, counting,
@@ -500,7 +510,8 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         if (timing) { HIP_TRY(ctx, next_event(ec)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); }
         cur = 1 - cur;
         const uint32_t ring = launched % kRing;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_count + ring, c_count[cur], 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpy2DAsync(ctx->h_count + ring * rtk::kQueues, sizeof(uint32_t), c_count[cur], kLine, sizeof(uint32_t), rtk::kQueues, hipMemcpyDeviceToHost,
+                                      ctx->stream));   // the kQueues pool sizes, one per line
         hipEvent_t ev = nullptr;
         HIP_TRY(ctx, next_event(ev));
         pending.push_back({ev, ring});
