@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     // queue of its block number; every counter exists once per queue, 128 bytes apart.
     if (blockIdx.x == 0 && threadIdx.x < kQueues) count_out_to_zero[threadIdx.x * kQStride] = 0u;   // the next k_shade appends to them
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_all = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t wave_all = blockIdx.x * (blockDim.x >> 6) + first_lane_u32(threadIdx.x >> 6);   // wave-uniform: keeps the queue bookkeeping in SGPRs
     const uint32_t q = DRAIN ? (blockIdx.x & (kQueues - 1u)) : (wave_all & (kQueues - 1u));
     const uint32_t qbase = q * rd.queue_cap;
     const uint32_t count = count_ptr[q * kQStride];
@@ -523,7 +523,19 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     // Short queue (the long tail of a render, hundreds of launches with a few thousand rays): a workgroup whose
     // waves own no static chunk has no dynamic chunk to fetch either — leave before staging the scene.
     const uint32_t wave_id = wave_all / kQueues;     // this wave's number among the waves of its queue
-    if (!DRAIN && __syncthreads_or((wave_id * chunk < count || head0 < count) ? 1 : 0) == 0) return;   // no wave of this workgroup has anything to do
+    if (!DRAIN) {
+        // Short queues (the long tail of a render): a workgroup none of whose waves owns a static chunk or could fetch a dynamic one
+        // leaves before staging the scene. Every thread evaluates the same test for all waves of the workgroup (no __syncthreads_or:
+        // its reduction scratch is static LDS, and the staged scene must start at LDS address 0).
+        bool any = false;
+        const uint32_t w0 = blockIdx.x * (blockDim.x >> 6);
+        for (uint32_t w = w0; w < w0 + (blockDim.x >> 6); ++w) {
+            const uint32_t cq = count_ptr[(w & (kQueues - 1u)) * kQStride];
+            const uint32_t ch = cq > kChunk * n_waves ? kChunk : max(64u, (cq / (2u * n_waves)) & ~63u);
+            any = any || (w / kQueues) * ch < cq || n_waves * ch < cq;
+        }
+        if (!any) return;
+    }
     if (DRAIN && (blockIdx.x / kQueues) * blockDim.x >= count) return;      // lane i of the queue's workgroups carries path i
     const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
     const float4* spheres = reinterpret_cast<const float4*>(sc.spheres);
