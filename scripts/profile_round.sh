@@ -1,10 +1,19 @@
-# On the GPU box: the evidence committed under profiles/ (kernel-trace stats of bench.py, PMC passes, all configs).
+# On the GPU box: the evidence committed under profiles/ for this round — rocprofv3 kernel-trace stats of bench.py, the PMC passes of the
+# bench workload (book-1, LDS-resident) and of the config-5 scene (compressed records in HBM), every BASELINE config, the three walks
+# of config 5, and one plain bench line. Everything lands in gpurun_out/prof2/ (copied to profiles/ afterwards, on the CPU side,
+# by scripts/collect_profiles.py).
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/prof
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/bench_stats -o run -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 > gpurun_out/prof/bench_under_rocprof.log 2>&1 || exit 1
-bash scripts/pmc_passes.sh R > gpurun_out/prof/pmc_summary.txt 2>&1 || exit 1
-timeout -k 10 400 python3 scripts/gpu_configs.py > gpurun_out/prof/configs.log 2>&1 || exit 1
-cp gpurun_out/configs.json gpurun_out/prof/configs.json
-timeout -k 10 500 python3 bench.py > gpurun_out/prof/bench.json 2> gpurun_out/prof/bench.err || exit 1
-cat gpurun_out/prof/bench.json
+mkdir -p gpurun_out/prof2
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof2/bench_stats -o run -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-variants > gpurun_out/prof2/bench_under_rocprof.json 2> gpurun_out/prof2/bench_under_rocprof.err || exit 1
+echo "kernel-trace done" >> gpurun_out/prof2/progress.log
+bash scripts/pmc_passes.sh R2 > gpurun_out/prof2/pmc_book1_summary.txt 2>&1 || exit 1
+echo "pmc book1 done" >> gpurun_out/prof2/progress.log
+bash scripts/pmc_c5.sh C5b 16 > gpurun_out/prof2/pmc_c5_summary.txt 2>&1 || exit 1
+echo "pmc c5 done" >> gpurun_out/prof2/progress.log
+timeout -k 10 400 python3 scripts/gpu_configs.py > gpurun_out/prof2/configs.log 2>&1 || exit 1
+cp gpurun_out/configs.json gpurun_out/prof2/configs.json
+timeout -k 10 300 python3 scripts/gpu_c5_top.py 32 > gpurun_out/prof2/c5_walks.log 2>&1 || exit 1
+echo "configs done" >> gpurun_out/prof2/progress.log
+timeout -k 10 500 python3 bench.py > gpurun_out/prof2/bench.json 2> gpurun_out/prof2/bench.err || exit 1
+cat gpurun_out/prof2/bench.json
