@@ -33,6 +33,7 @@ VARIANTS = {
     "c8192": ["RT_CHUNK=8192"],
     "c2048b24r24": ["RT_CHUNK=2048", "RT_LEAF_BATCH=24", "RT_REFILL_MIN=24"],
     "s2": ["RT_STEPS=2"],
+    "s4": ["RT_STEPS=4"],
     "s8": ["RT_STEPS=8"],
     "s6": ["RT_STEPS=6"],
     "s3": ["RT_STEPS=3"],
