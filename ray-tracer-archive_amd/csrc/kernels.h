@@ -36,6 +36,11 @@ struct SceneDev {
     const rtd::PerlinTable* perlins;
     const rtd::Image* images; const uint8_t* image_bytes;
     const rtd::Light* lights; uint32_t n_lights;
+    // k_shade's small tables as ONE blob (spheres, sphere meta, rects, rect meta, moving, moving meta, materials, transforms, wrapper
+    // chains, lights, textures; every part 16-byte aligned), staged into LDS by each k_shade workgroup when it fits: the chain of
+    // dependent look-ups hit -> meta -> wrap -> transform -> primitive -> material -> lights then runs at LDS, not L2, latency.
+    const rtd::Float4* shade_blob; uint32_t shade_blob_bytes;   // 0: no staging
+    uint32_t sb_spheres, sb_sphere_meta, sb_rects, sb_rect_meta, sb_moving, sb_moving_meta, sb_mat_a, sb_mat_b, sb_xforms, sb_wraps, sb_lights, sb_textures;   // byte offsets
 };
 
 // Path pool: structure of arrays, one lane-contiguous record per array and slot.

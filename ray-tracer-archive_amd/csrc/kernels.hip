@@ -1383,6 +1383,26 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
                                                 uint32_t* __restrict__ count_out, uint32_t* __restrict__ next_work, uint32_t* __restrict__ head_to_zero,
                                                 unsigned long long* __restrict__ counters) {
     __shared__ uint32_t s_scan[kShadeThreads / 64 + 1];
+    extern __shared__ float4 s_tables[];
+    // the scene's small tables, staged once per workgroup (LDS-DMA, linear copy): shade_segment then follows its chain of dependent
+    // look-ups through LDS. The pointers become generic pointers into LDS (flat loads), the code that uses them does not change.
+    if (sc.shade_blob_bytes != 0u) {
+        const uint32_t tot = sc.shade_blob_bytes >> 4, wave = threadIdx.x >> 6, ln = threadIdx.x & 63u, nw = blockDim.x >> 6;
+        for (uint32_t base = wave * 64u; base < tot; base += nw * 64u) {
+            const uint32_t k = base + ln;
+            if (k < tot) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sc.shade_blob + k),
+                                                          (__attribute__((address_space(3))) void*)(s_tables + base), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* t = reinterpret_cast<const char*>(s_tables);
+        sc.spheres = reinterpret_cast<const Float4*>(t + sc.sb_spheres); sc.sphere_meta = reinterpret_cast<const uint32_t*>(t + sc.sb_sphere_meta);
+        sc.rects = reinterpret_cast<const Float4*>(t + sc.sb_rects); sc.rect_meta = reinterpret_cast<const uint32_t*>(t + sc.sb_rect_meta);
+        sc.moving = reinterpret_cast<const Float4*>(t + sc.sb_moving); sc.moving_meta = reinterpret_cast<const uint32_t*>(t + sc.sb_moving_meta);
+        sc.mat_a = reinterpret_cast<const Float4*>(t + sc.sb_mat_a); sc.mat_b = reinterpret_cast<const uint32_t*>(t + sc.sb_mat_b);
+        sc.xforms = reinterpret_cast<const rtd::Xform*>(t + sc.sb_xforms); sc.wraps = reinterpret_cast<const rtd::Wrap*>(t + sc.sb_wraps);
+        sc.lights = reinterpret_cast<const rtd::Light*>(t + sc.sb_lights); sc.textures = reinterpret_cast<const rtd::Texture*>(t + sc.sb_textures);
+    }
     // workgroup b shades 512 paths of queue b mod kQueues and compacts the survivors into the same queue of the other pool: one
     // counter pair per queue, so the same-address atomics of all the workgroups (one per 512 paths, ~11 ns each at the memory side:
     // 29 ms of a 39 ms kernel with ONE pair) spread over kQueues addresses
@@ -1619,8 +1639,8 @@ template <uint32_t FEAT>
 static void launch_shade_t(uint32_t blocks, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, const uint32_t* count_in,
                            uint32_t* count_out, uint32_t* next_work, uint32_t* hz, unsigned long long* counters, bool count,
                            hipStream_t stream) {
-    if (count) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
-    else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(blocks), dim3(kShadeThreads), 0, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
+    if (count) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(blocks), dim3(kShadeThreads), sc.shade_blob_bytes, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
+    else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(blocks), dim3(kShadeThreads), sc.shade_blob_bytes, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
 }
 
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,

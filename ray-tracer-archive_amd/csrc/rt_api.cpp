@@ -295,6 +295,22 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->media, cs.media);
     up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
     up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
+    // k_shade's small tables as one blob for LDS staging (kernels.h SceneDev::shade_blob): only when it is small. RT_SHADE_LDS=0 turns it off.
+    std::vector<unsigned char> blob;
+    uint32_t sb[12] = {0};
+    {
+        auto put = [&](const void* p, size_t bytes) { const uint32_t at = (uint32_t)blob.size(); blob.resize((blob.size() + bytes + 15) & ~(size_t)15, 0); if (bytes) std::memcpy(blob.data() + at, p, bytes); return at; };
+        sb[0] = put(cs.spheres.data(), cs.spheres.size() * 16); sb[1] = put(cs.sphere_meta.data(), cs.sphere_meta.size() * 4);
+        sb[2] = put(cs.rects.data(), cs.rects.size() * 16); sb[3] = put(cs.rect_meta.data(), cs.rect_meta.size() * 4);
+        sb[4] = put(cs.moving.data(), cs.moving.size() * 16); sb[5] = put(cs.moving_meta.data(), cs.moving_meta.size() * 4);
+        sb[6] = put(cs.mat_a.data(), cs.mat_a.size() * 16); sb[7] = put(cs.mat_b.data(), cs.mat_b.size() * 4);
+        sb[8] = put(cs.xforms.data(), cs.xforms.size() * sizeof(rtd::Xform)); sb[9] = put(cs.wraps.data(), cs.wraps.size() * sizeof(rtd::Wrap));
+        sb[10] = put(cs.lights.data(), cs.lights.size() * sizeof(rtd::Light)); sb[11] = put(cs.textures.data(), cs.textures.size() * sizeof(rtd::Texture));
+        bool on = blob.size() <= 32 * 1024;
+        if (const char* e = getenv("RT_SHADE_LDS")) on = on && e[0] != '0';
+        if (!on) blob.clear();
+    }
+    if (!blob.empty()) up(s->shade_blob, blob);
     if (r == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = set_err(ctx, RT_ERR_DEVICE, "scene upload failed");
     if (r != RT_OK) { rt_scene_destroy(ctx, s); return r; }
     rtk::SceneDev& d = s->dev;
@@ -312,6 +328,9 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     d.textures = (const rtd::Texture*)s->textures.p; d.perlins = (const rtd::PerlinTable*)s->perlins.p;
     d.images = (const rtd::Image*)s->images.p; d.image_bytes = (const uint8_t*)s->image_bytes.p;
     d.lights = (const rtd::Light*)s->lights.p; d.n_lights = (uint32_t)cs.lights.size();
+    d.shade_blob = blob.empty() ? nullptr : (const rtd::Float4*)s->shade_blob.p; d.shade_blob_bytes = (uint32_t)blob.size();
+    d.sb_spheres = sb[0]; d.sb_sphere_meta = sb[1]; d.sb_rects = sb[2]; d.sb_rect_meta = sb[3]; d.sb_moving = sb[4]; d.sb_moving_meta = sb[5];
+    d.sb_mat_a = sb[6]; d.sb_mat_b = sb[7]; d.sb_xforms = sb[8]; d.sb_wraps = sb[9]; d.sb_lights = sb[10]; d.sb_textures = sb[11];
     const uint32_t f = scene_features(cs);
     s->features = f;
     s->in_lds = in_lds; s->lds_bytes = lds_scene_bytes(cs);
@@ -328,7 +347,7 @@ int rt_scene_destroy(RtCtx* ctx, RtScene* s) {
     if (!s) return RT_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     DevBuf* all[] = {&s->nodes, &s->spheres, &s->sphere_meta, &s->moving, &s->moving_meta, &s->rects, &s->rect_meta, &s->tris, &s->tri_meta, &s->media,
-                     &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights, &s->top_nodes};
+                     &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights, &s->top_nodes, &s->shade_blob};
     for (DevBuf* b : all) b->release();
     delete s;
     return RT_OK;
