@@ -40,6 +40,9 @@ struct SceneDev {
     // chains, lights, textures; every part 16-byte aligned), staged into LDS by each k_shade workgroup when it fits: the chain of
     // dependent look-ups hit -> meta -> wrap -> transform -> primitive -> material -> lights then runs at LDS, not L2, latency.
     const rtd::Float4* shade_blob; uint32_t shade_blob_bytes;   // 0: no staging
+    // the same for k_extend's primitive pass on LDS-resident scenes: rects, moving spheres, transforms, media behind the records and the
+    // sphere data (book-3 Cornell tests its 12 rects on every segment)
+    const rtd::Float4* ext_blob; uint32_t ext_blob_bytes; uint32_t eb_rects, eb_moving, eb_xforms, eb_media;
     uint32_t sb_spheres, sb_sphere_meta, sb_rects, sb_rect_meta, sb_moving, sb_moving_meta, sb_mat_a, sb_mat_b, sb_xforms, sb_wraps, sb_lights, sb_textures;   // byte offsets
 };
 

@@ -545,19 +545,26 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         // shape of LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, LDS address = wave base + lane * 16, no VGPR round
         // trip); all pieces in flight, then one wait + barrier
         const float4* src0 = LDS ? nodes : reinterpret_cast<const float4*>(sc.top_nodes);
-        const uint32_t n4 = 2u * (LDS ? sc.n_records : sc.n_top), s4 = LDS ? sc.n_spheres : 0u, tot = n4 + s4;
+        const uint32_t n4 = 2u * (LDS ? sc.n_records : sc.n_top), s4 = LDS ? sc.n_spheres : 0u, b4 = LDS ? (sc.ext_blob_bytes >> 4) : 0u, tot = n4 + s4 + b4;
         const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63u, nw = blockDim.x >> 6;
         for (uint32_t base = wave * 64u; base < tot; base += nw * 64u) {
             const uint32_t i = base + ln;
             if (i < tot) {
-                const float4* src = i < n4 ? src0 + i : spheres + (i - n4);
+                const float4* src = i < n4 ? src0 + i : (i < n4 + s4 ? spheres + (i - n4) : reinterpret_cast<const float4*>(sc.ext_blob) + (i - n4 - s4));
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(lds + base), 16, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (LDS) { nodes = lds; spheres = lds + n4; }
+        if (LDS) {
+            nodes = lds; spheres = lds + n4;
+            if (b4 != 0u) {   // the primitive pass's other tables, through generic pointers into LDS
+                const char* t = reinterpret_cast<const char*>(lds + n4 + s4);
+                sc.rects = reinterpret_cast<const Float4*>(t + sc.eb_rects); sc.moving = reinterpret_cast<const Float4*>(t + sc.eb_moving);
+                sc.xforms = reinterpret_cast<const rtd::Xform*>(t + sc.eb_xforms); sc.media = reinterpret_cast<const rtd::Medium*>(t + sc.eb_media);
+            }
+        }
     }
     // the three kinds of self-loop records, by address (device_nodes): DONE, IDLE, then the park twins
     const uint32_t special = top_bytes + sc.n_nodes * 32u, a_done = special, a_idle = special + 32u, a_twins = special + 64u;
@@ -1540,7 +1547,7 @@ static hipError_t launch_extend_g(uint32_t n_groups, size_t lds_bytes, const Sce
 template <int MODE, uint32_t FEAT, bool COUNT>
 static hipError_t launch_drain_c(const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, uint32_t max_count, const uint32_t* count_ptr, uint32_t* head, uint32_t* cz,
                                  uint32_t* next_work, unsigned long long* counters, hipStream_t stream) {
-    const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
+    const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u + sc.ext_blob_bytes) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
     constexpr uint32_t T = kExtendThreads;
     // max_count = upper bound of the paths in ONE queue
     hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, T, true>), dim3(kQueues * ((max_count + T - 1u) / T)), dim3(T), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd, next_work);
@@ -1549,7 +1556,7 @@ static hipError_t launch_drain_c(const SceneDev& sc, const PoolDev& pool, const 
 template <int MODE, uint32_t FEAT, bool COUNT>
 static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
-    const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
+    const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u + sc.ext_blob_bytes) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
     constexpr bool kNoLds = MODE == M_HBM || MODE == M_C16;
     // workgroup sizes compiled for this mode: 256 threads always; 512 and 1024 where an LDS copy limits the groups per CU (a
     // 100 KB scene allows ONE group per CU: only a 1024-thread group then keeps 16 waves on it)

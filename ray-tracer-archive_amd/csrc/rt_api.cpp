@@ -312,6 +312,18 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
         if (!on) blob.clear();
     }
     if (!blob.empty()) up(s->shade_blob, blob);
+    // k_extend's primitive pass tables for LDS-resident scenes (kernels.h SceneDev::ext_blob): small ones only, inside the LDS budget
+    std::vector<unsigned char> eblob;
+    uint32_t eb[4] = {0};
+    if (in_lds) {
+        auto put = [&](const void* p, size_t bytes) { const uint32_t at = (uint32_t)eblob.size(); eblob.resize((eblob.size() + bytes + 15) & ~(size_t)15, 0); if (bytes) std::memcpy(eblob.data() + at, p, bytes); return at; };
+        eb[0] = put(cs.rects.data(), cs.rects.size() * 16); eb[1] = put(cs.moving.data(), cs.moving.size() * 16);
+        eb[2] = put(cs.xforms.data(), cs.xforms.size() * sizeof(rtd::Xform)); eb[3] = put(cs.media.data(), cs.media.size() * sizeof(rtd::Medium));
+        bool on = eblob.size() <= 8 * 1024 && lds_scene_bytes(cs) + eblob.size() <= kLdsSceneBudget && !(cs.rects.empty() && cs.moving.empty() && cs.media.empty());
+        if (const char* e = getenv("RT_EXTEND_LDS_TABLES")) on = on && e[0] != '0';
+        if (!on) eblob.clear();
+    }
+    if (!eblob.empty()) up(s->ext_blob, eblob);
     if (r == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = set_err(ctx, RT_ERR_DEVICE, "scene upload failed");
     if (r != RT_OK) { rt_scene_destroy(ctx, s); return r; }
     rtk::SceneDev& d = s->dev;
@@ -331,6 +343,8 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     d.lights = (const rtd::Light*)s->lights.p; d.n_lights = (uint32_t)cs.lights.size();
     d.shade_blob = blob.empty() ? nullptr : (const rtd::Float4*)s->shade_blob.p; d.shade_blob_bytes = (uint32_t)blob.size();
     d.sb_spheres = sb[0]; d.sb_sphere_meta = sb[1]; d.sb_rects = sb[2]; d.sb_rect_meta = sb[3]; d.sb_moving = sb[4]; d.sb_moving_meta = sb[5];
+    d.ext_blob = eblob.empty() ? nullptr : (const rtd::Float4*)s->ext_blob.p; d.ext_blob_bytes = (uint32_t)eblob.size();
+    d.eb_rects = eb[0]; d.eb_moving = eb[1]; d.eb_xforms = eb[2]; d.eb_media = eb[3];
     d.sb_mat_a = sb[6]; d.sb_mat_b = sb[7]; d.sb_xforms = sb[8]; d.sb_wraps = sb[9]; d.sb_lights = sb[10]; d.sb_textures = sb[11];
     const uint32_t f = scene_features(cs);
     s->features = f;
@@ -348,7 +362,7 @@ int rt_scene_destroy(RtCtx* ctx, RtScene* s) {
     if (!s) return RT_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     DevBuf* all[] = {&s->nodes, &s->spheres, &s->sphere_meta, &s->moving, &s->moving_meta, &s->rects, &s->rect_meta, &s->tris, &s->tri_meta, &s->media,
-                     &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights, &s->top_nodes, &s->shade_blob};
+                     &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights, &s->top_nodes, &s->shade_blob, &s->ext_blob};
     for (DevBuf* b : all) b->release();
     delete s;
     return RT_OK;
