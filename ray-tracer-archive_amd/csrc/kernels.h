@@ -43,6 +43,7 @@ struct SceneDev {
     // the same for k_extend's primitive pass on LDS-resident scenes: rects, moving spheres, transforms, media behind the records and the
     // sphere data (book-3 Cornell tests its 12 rects on every segment)
     const rtd::Float4* ext_blob; uint32_t ext_blob_bytes; uint32_t eb_rects, eb_moving, eb_xforms, eb_media;
+    uint32_t eb_rect_stride;   // 32: the rect table as it is (sc.rects is redirected too); 24: without the two padding words, where only that fits
     uint32_t sb_spheres, sb_sphere_meta, sb_rects, sb_rect_meta, sb_moving, sb_moving_meta, sb_mat_a, sb_mat_b, sb_xforms, sb_wraps, sb_lights, sb_textures;   // byte offsets
 };
 

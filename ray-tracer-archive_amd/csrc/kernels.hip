@@ -561,7 +561,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             nodes = lds; spheres = lds + n4;
             if (b4 != 0u) {   // the primitive pass's other tables, through generic pointers into LDS
                 const char* t = reinterpret_cast<const char*>(lds + n4 + s4);
-                sc.rects = reinterpret_cast<const Float4*>(t + sc.eb_rects); sc.moving = reinterpret_cast<const Float4*>(t + sc.eb_moving);
+                if (sc.eb_rect_stride == 32u) sc.rects = reinterpret_cast<const Float4*>(t + sc.eb_rects);   // a medium's box boundary reads sc.rects
+                sc.moving = reinterpret_cast<const Float4*>(t + sc.eb_moving);
                 sc.xforms = reinterpret_cast<const rtd::Xform*>(t + sc.eb_xforms); sc.media = reinterpret_cast<const rtd::Medium*>(t + sc.eb_media);
             }
         }
@@ -636,6 +637,16 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     auto load_twin = [&](uint32_t off) -> uint2 {
         if constexpr (LDS) { const U2V v = *reinterpret_cast<lds_u2>(off); return make_uint2(v.x, v.y); }
         else return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(nodes) + (off - top_bytes));
+    };
+    // rect `idx` of the primitive pass: a0 a1 b0 b1 | k axis, from the staged table (LDS address, stride 32 or 24) or from HBM
+    const uint32_t rects_lds = (LDS && sc.ext_blob_bytes != 0u) ? (2u * sc.n_records + sc.n_spheres) * 16u + sc.eb_rects : 0u, rect_stride = sc.eb_rect_stride;
+    auto load_rect = [&](uint32_t idx, Float4& r0, Float4& r1) {
+        if (LDS && rects_lds != 0u) {
+            const uint32_t at = rects_lds + idx * rect_stride;
+            const U2V p0 = *reinterpret_cast<lds_u2>(at), p1 = *reinterpret_cast<lds_u2>(at + 8u), p2 = *reinterpret_cast<lds_u2>(at + 16u);
+            r0 = Float4{__uint_as_float(p0.x), __uint_as_float(p0.y), __uint_as_float(p1.x), __uint_as_float(p1.y)};
+            r1 = Float4{__uint_as_float(p2.x), __uint_as_float(p2.y), 0.f, 0.f};
+        } else { r0 = sc.rects[2 * idx]; r1 = sc.rects[2 * idx + 1]; }
     };
     // ---- DRAIN: the lane's path, for its whole life ----
     PathState ps{}; Rng g; g.s = 0; uint32_t depth = 0, sample = 0;
@@ -872,7 +883,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                 }
             } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
                 for (uint32_t k = 0; k < cnt; ++k) {
-                    const Float4 r0 = sc.rects[2 * (first + k)], r1 = sc.rects[2 * (first + k) + 1];
+                    Float4 r0, r1;
+                    load_rect(first + k, r0, r1);
                     float t, ha, hb;
                     if (COUNT) c_prims[2]++;
                     const uint32_t id = (rtd::LT_RECT << 28) | (first + k);

@@ -314,14 +314,29 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     if (!blob.empty()) up(s->shade_blob, blob);
     // k_extend's primitive pass tables for LDS-resident scenes (kernels.h SceneDev::ext_blob): small ones only, inside the LDS budget
     std::vector<unsigned char> eblob;
-    uint32_t eb[4] = {0};
-    if (in_lds) {
-        auto put = [&](const void* p, size_t bytes) { const uint32_t at = (uint32_t)eblob.size(); eblob.resize((eblob.size() + bytes + 15) & ~(size_t)15, 0); if (bytes) std::memcpy(eblob.data() + at, p, bytes); return at; };
-        eb[0] = put(cs.rects.data(), cs.rects.size() * 16); eb[1] = put(cs.moving.data(), cs.moving.size() * 16);
-        eb[2] = put(cs.xforms.data(), cs.xforms.size() * sizeof(rtd::Xform)); eb[3] = put(cs.media.data(), cs.media.size() * sizeof(rtd::Medium));
-        bool on = eblob.size() <= 8 * 1024 && lds_scene_bytes(cs) + eblob.size() <= kLdsSceneBudget && !(cs.rects.empty() && cs.moving.empty() && cs.media.empty());
-        if (const char* e = getenv("RT_EXTEND_LDS_TABLES")) on = on && e[0] != '0';
-        if (!on) eblob.clear();
+    uint32_t eb[4] = {0}, eb_rect_stride = 32;
+    if (in_lds && !(cs.rects.empty() && cs.moving.empty() && cs.media.empty())) {
+        // staged once per workgroup and launch (persistent waves), so size only matters against the 160 KB of the CU: the rect table as
+        // it is (2 x 16 B per rect) where that fits, else without its two padding words (book-2 final scene: 2401 rects behind 91 KB of
+        // records and spheres)
+        const size_t room = 160 * 1024 - lds_scene_bytes(cs);
+        const size_t n_rects = cs.rects.size() / 2;
+        for (uint32_t stride : {32u, 24u}) {
+            eblob.clear();
+            auto put = [&](const void* p, size_t bytes) { const uint32_t at = (uint32_t)eblob.size(); eblob.resize((eblob.size() + bytes + 15) & ~(size_t)15, 0); if (bytes) std::memcpy(eblob.data() + at, p, bytes); return at; };
+            if (stride == 32u) eb[0] = put(cs.rects.data(), n_rects * 32);
+            else {
+                std::vector<float> packed(n_rects * 6);
+                for (size_t i = 0; i < n_rects; ++i) { std::memcpy(&packed[6 * i], &cs.rects[2 * i], 16); std::memcpy(&packed[6 * i + 4], &cs.rects[2 * i + 1], 8); }
+                eb[0] = put(packed.data(), packed.size() * 4);
+            }
+            eb[1] = put(cs.moving.data(), cs.moving.size() * 16);
+            eb[2] = put(cs.xforms.data(), cs.xforms.size() * sizeof(rtd::Xform)); eb[3] = put(cs.media.data(), cs.media.size() * sizeof(rtd::Medium));
+            eb_rect_stride = stride;
+            if (eblob.size() <= room) break;
+            eblob.clear();
+        }
+        if (const char* e = getenv("RT_EXTEND_LDS_TABLES")) if (e[0] == '0') eblob.clear();
     }
     if (!eblob.empty()) up(s->ext_blob, eblob);
     if (r == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = set_err(ctx, RT_ERR_DEVICE, "scene upload failed");
@@ -344,7 +359,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     d.shade_blob = blob.empty() ? nullptr : (const rtd::Float4*)s->shade_blob.p; d.shade_blob_bytes = (uint32_t)blob.size();
     d.sb_spheres = sb[0]; d.sb_sphere_meta = sb[1]; d.sb_rects = sb[2]; d.sb_rect_meta = sb[3]; d.sb_moving = sb[4]; d.sb_moving_meta = sb[5];
     d.ext_blob = eblob.empty() ? nullptr : (const rtd::Float4*)s->ext_blob.p; d.ext_blob_bytes = (uint32_t)eblob.size();
-    d.eb_rects = eb[0]; d.eb_moving = eb[1]; d.eb_xforms = eb[2]; d.eb_media = eb[3];
+    d.eb_rect_stride = eb_rect_stride; d.eb_rects = eb[0]; d.eb_moving = eb[1]; d.eb_xforms = eb[2]; d.eb_media = eb[3];
     d.sb_mat_a = sb[6]; d.sb_mat_b = sb[7]; d.sb_xforms = sb[8]; d.sb_wraps = sb[9]; d.sb_lights = sb[10]; d.sb_textures = sb[11];
     const uint32_t f = scene_features(cs);
     s->features = f;
