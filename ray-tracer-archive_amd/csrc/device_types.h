@@ -31,6 +31,7 @@ enum LeafType : uint32_t {
     LT_EXIT = 7      // first = xform id to restore (0 = world ray)
 };
 constexpr uint32_t LEAF_MAX_COUNT = 15;
+constexpr uint32_t MAX_PROLOGUE = 4;   // leaf payloads tested at the start of every walk instead of being met by it
 constexpr uint32_t LEAF_MAX_FIRST = (1u << 24) - 1;
 inline uint32_t make_leaf(uint32_t type, uint32_t first, uint32_t count) { return (type << 28) | (count << 24) | first; }
 

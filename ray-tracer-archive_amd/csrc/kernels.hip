@@ -274,7 +274,7 @@ DEVI V3 moving_center(Float4 m0, Float4 m1, Float4 m2, float time) {           /
 }
 // XyRect/XzRect/YzRect::hit (aarect.rs:31-48, 81-98, 150-167)
 DEVI bool rect_hit(V3 o, V3 d, Float4 r0, Float4 r1, float tmin, float tmax, float& t, float& ha, float& hb) {
-    const int kaxis = (int)r1.y;
+    const int kaxis = (int)r1.y & 3;      // + 4 on the first side of a box (scene_compile.cpp add_box_rects)
     const int ia = kaxis == 0 ? 1 : 0, ib = kaxis == 2 ? 1 : 2;
     const float tt = fdiv(r1.x - comp(o, kaxis), comp(d, kaxis));
     if (tt < tmin || tt > tmax) return false;
@@ -284,6 +284,25 @@ DEVI bool rect_hit(V3 o, V3 d, Float4 r0, Float4 r1, float tmin, float tmax, flo
     if (a < r0.x || a > r0.y || b < r0.z || b > r0.w) return false;
     t = tt; ha = a; hb = b;
     return true;
+}
+// The six sides of a box (boxes.rs:17-74: z1 z0 y1 y0 x1 x0) as HittableList::hit walks them: six rect tests in that order with t_max
+// shrinking, from the box's bounds — without six record loads and six dynamically indexed axes. `skip` = the side the ray starts on
+// (>= 6: none); `which` = the side that holds the closest hit.
+DEVI bool box_sides_hit(V3 o, V3 d, float x0, float x1, float y0, float y1, float z0, float z1, float tmin, float& tmax, uint32_t skip, uint32_t& which) {
+    bool any = false;
+    auto side = [&](float plane, float ok, float dk, float oa, float da, float a0, float a1, float ob, float db, float b0, float b1, uint32_t s) {
+        const float tt = fdiv(plane - ok, dk);
+        const float aa = oa + tt * da, bb = ob + tt * db;
+        const bool h = s != skip && !(tt < tmin || tt > tmax) && fabsf(tt) < kInf && !(aa < a0 || aa > a1 || bb < b0 || bb > b1);
+        if (h) { tmax = tt; which = s; any = true; }
+    };
+    side(z1, o.z, d.z, o.x, d.x, x0, x1, o.y, d.y, y0, y1, 0u);
+    side(z0, o.z, d.z, o.x, d.x, x0, x1, o.y, d.y, y0, y1, 1u);
+    side(y1, o.y, d.y, o.x, d.x, x0, x1, o.z, d.z, z0, z1, 2u);
+    side(y0, o.y, d.y, o.x, d.x, x0, x1, o.z, d.z, z0, z1, 3u);
+    side(x1, o.x, d.x, o.y, d.y, y0, y1, o.z, d.z, z0, z1, 4u);
+    side(x0, o.x, d.x, o.y, d.y, y0, y1, o.z, d.z, z0, z1, 5u);
+    return any;
 }
 // Triangle (not in the reference): Moeller-Trumbore, inclusive interval, u,v = barycentrics
 DEVI bool tri_hit(V3 o, V3 d, V3 v0, V3 v1, V3 v2, float tmin, float tmax, float& t, float& bu, float& bv) {
@@ -314,6 +333,13 @@ DEVI bool boundary_hit(const SceneDev& sc, const rtd::Medium& m, V3 o, V3 d, flo
         return sphere_roots(o, d, a, f4xyz(s), s.w, tmin, tmax, t);
     }
     bool any = false; float best = tmax;
+    if (m.boundary_count == 6u) {   // a box (scene_compile.cpp emit_medium: add_box_rects)
+        const Float4 r0 = sc.rects[2 * m.boundary_first], r1 = sc.rects[2 * m.boundary_first + 1];
+        uint32_t which;
+        any = box_sides_hit(o, d, r0.x, r0.y, r0.z, r0.w, sc.rects[2 * m.boundary_first + 3].x, r1.x, tmin, best, 6u, which);
+        t = best;
+        return any;
+    }
     for (uint32_t k = 0; k < m.boundary_count; ++k) {
         const Float4 r0 = sc.rects[2 * (m.boundary_first + k)], r1 = sc.rects[2 * (m.boundary_first + k) + 1];
         float tt, ha, hb;
@@ -603,6 +629,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 
 #ifdef RT_STAMPS
     unsigned long long st_refill = 0, st_node = 0, st_prim = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
+    unsigned long long st_pass[6] = {0, 0, 0, 0, 0, 0}, st_lanes[6] = {0, 0, 0, 0, 0, 0};
 #define STAMP(x) x = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(x)
@@ -648,10 +675,37 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             r1 = Float4{__uint_as_float(p2.x), __uint_as_float(p2.y), 0.f, 0.f};
         } else { r0 = sc.rects[2 * idx]; r1 = sc.rects[2 * idx + 1]; }
     };
+    auto load_rect_plane = [&](uint32_t idx) -> float {       // the plane coordinate k alone
+        if (LDS && rects_lds != 0u) return *reinterpret_cast<const __attribute__((address_space(3))) float*>(rects_lds + idx * rect_stride + 16u);
+        return sc.rects[2 * idx + 1].x;
+    };
     // ---- DRAIN: the lane's path, for its whole life ----
     PathState ps{}; Rng g; g.s = 0; uint32_t depth = 0, sample = 0;
     unsigned long long c_segments = 0, c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
     const bool with_acc = rd.block_shift != 0u;
+    // the root list's every-ray members (SceneDev::prologue), for a lane whose walk begins: world space, t_max = inf
+    auto prologue = [&]() {
+        if constexpr ((FEAT & (F_MOVING | F_MEDIUM)) != 0u) {
+#pragma unroll
+            for (uint32_t k = 0; k < rtd::MAX_PROLOGUE; ++k) {      // constant indices: `sc` stays in registers
+                if (k >= sc.n_prologue) break;
+                const uint32_t pl = sc.prologue[k], type = pl >> 28, first = pl & rtd::LEAF_MAX_FIRST;
+                float t;
+                if ((FEAT & F_MOVING) && type == rtd::LT_MOVING) {
+                    const Float4 m0 = sc.moving[3 * first], m1 = sc.moving[3 * first + 1], m2 = sc.moving[3 * first + 2];
+                    if (COUNT) c_prims[1]++;
+                    const uint32_t id = (rtd::LT_MOVING << 28) | first;
+                    const V3 mc = moving_center(m0, m1, m2, tm);
+                    const bool h = (id == from) ? sphere_hit_from_surface(o, d, a, mc, m0.w, kTMin, tmax, t) : sphere_hit(o, d, a, mc, m0.w, kTMin, tmax, t);
+                    if (h) { tmax = t; hit_prim = id; }
+                } else if ((FEAT & F_MEDIUM) && type == rtd::LT_MEDIUM) {
+                    const rtd::Medium m = sc.media[first];
+                    if (COUNT) c_prims[4]++;
+                    if (medium_hit(sc, m, o, d, kTMin, tmax, u01(medium_bits(mkey, seg, m.medium_id)), t)) { tmax = t; hit_prim = (rtd::LT_MEDIUM << 28) | first; }
+                }
+            }
+        }
+    };
     // a ray the lane has just been given (by the pool or by shading): per-ray constants, walk from the root
     auto begin_walk = [&]() {
         if (C16) set_grid_ray(); else set_slab_ray(o, d, sr);
@@ -663,6 +717,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             mkey = path_base(rd.seed, (uint64_t)it.y * rd.width + it.x, sample);
         }
         from = ps.from; tmax = kInf; hit_prim = rtd::HIT_NONE; go_root();
+        prologue();
     };
     if (DRAIN) {
         const uint32_t i = (blockIdx.x / kQueues) * blockDim.x + threadIdx.x;
@@ -710,6 +765,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                         mkey = path_base(rd.seed, (uint64_t)it.y * rd.width + it.x, sd >> 8);
                     }
                     tmax = kInf; hit_prim = rtd::HIT_NONE; go_root();   // address 0 = the root (the first record, or its copy in the top)
+                    prologue();
                 }
                 w_next += take;
             }
@@ -824,7 +880,11 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #endif
         // ---- primitive pass: when enough lanes hold a leaf, or nobody can walk any further ----
         const uint64_t pm = __ballot(pl != 0u);
+#ifdef RT_SERVE_BEST
+        bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(is_walking()) == 0ull);
+#else
         const bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(is_walking()) == 0ull);
+#endif
         // Scenes with four or more primitive kinds (book-2 final: spheres, a moving sphere, rects, media): a pass serves ONE
         // kind, the one most lanes wait with; the others stay parked and win a later pass. Every kind's code then runs with
         // as many lanes as the wave can give it instead of several kinds back to back with a handful of lanes each
@@ -839,7 +899,20 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                 const uint32_t c = (uint32_t)__popcll(__ballot(ty == k));
                 if (c > best) { best = c; serve = k; }
             }
+#ifdef RT_SERVE_BEST
+            do_prims = (int)best >= RT_SERVE_BEST || __ballot(is_walking()) == 0ull;
+#endif
         }
+#ifdef RT_STAMPS
+        // passes and the lanes they serve, per kind (RT_STAMPS builds run without COUNT: its slots carry these)
+        if (do_prims) {
+            for (uint32_t k = rtd::LT_SPHERE; k <= rtd::LT_MEDIUM; ++k) {
+                const uint32_t c = (uint32_t)__popcll(__ballot(pl != 0u && (pl >> 28) == k && (serve == 0u || k == serve)));
+                if (c != 0u && lane == 0u) { st_pass[k - 1u] += 1ull; st_lanes[k - 1u] += c; }
+            }
+            if (lane == 0u) st_pass[5]++;
+        }
+#endif
         if (do_prims && pl != 0u && (serve == 0u || (pl >> 28) == serve)) {
             const uint32_t type = pl >> 28, cnt = (pl >> 24) & 15u, first = pl & rtd::LEAF_MAX_FIRST;
             move_on();                                            // the record after the leaf, once its primitives are tested
@@ -882,15 +955,25 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     if (h) { tmax = t; hit_prim = id; }
                 }
             } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
-                for (uint32_t k = 0; k < cnt; ++k) {
+                for (uint32_t k = 0; k < cnt;) {
                     Float4 r0, r1;
                     load_rect(first + k, r0, r1);
-                    float t, ha, hb;
-                    if (COUNT) c_prims[2]++;
                     const uint32_t id = (rtd::LT_RECT << 28) | (first + k);
-                    // a ray that starts on this rect's plane meets it at t = 0 < t_min exactly; in f32 (after an
-                    // instance transform's round trip) t = rounding / d_k can pass t_min
-                    if (id != from && rect_hit(o, d, r0, r1, kTMin, tmax, t, ha, hb)) { tmax = t; hit_prim = id; }
+                    if ((int)r1.y >= 4) {
+                        // the six sides of a box, all of them in this leaf: every bound is in the first side's record but z0
+                        const float z0 = load_rect_plane(first + k + 1u);
+                        if (COUNT) c_prims[2] += 6ull;
+                        uint32_t which;
+                        if (box_sides_hit(o, d, r0.x, r0.y, r0.z, r0.w, z0, r1.x, kTMin, tmax, from - id, which)) hit_prim = id + which;
+                        k += 6u;
+                    } else {
+                        float t, ha, hb;
+                        if (COUNT) c_prims[2]++;
+                        // a ray that starts on this rect's plane meets it at t = 0 < t_min exactly; in f32 (after an
+                        // instance transform's round trip) t = rounding / d_k can pass t_min
+                        if (id != from && rect_hit(o, d, r0, r1, kTMin, tmax, t, ha, hb)) { tmax = t; hit_prim = id; }
+                        k += 1u;
+                    }
                 }
             } else if ((FEAT & F_MOVING) && type == rtd::LT_MOVING) {
                 for (uint32_t k = 0; k < cnt; ++k) {
@@ -984,6 +1067,10 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     if ((threadIdx.x & 63u) == 0u) {
         atomicAdd(&counters[CTR_DEBUG + 0], st_refill); atomicAdd(&counters[CTR_DEBUG + 1], st_node); atomicAdd(&counters[CTR_DEBUG + 2], st_prim);
         atomicAdd(&counters[CTR_DEBUG + 3], __builtin_amdgcn_s_memtime() - st_t0); atomicAdd(&counters[CTR_DEBUG + 4], 1ull);
+        if (!COUNT) {
+            atomicAdd(&counters[CTR_NODE_TESTS], st_pass[5]);
+            for (int k = 0; k < 5; ++k) atomicAdd(&counters[CTR_PRIM_TESTS + k], (st_pass[k] << 40) | st_lanes[k]);
+        }
     }
 #endif
     if (COUNT) {
@@ -1247,7 +1334,7 @@ DEVI uint32_t shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& 
                 if (FEAT & F_TEX) sphere_uv(outward, hu, hv);               // :62 (only textures read u,v)
             } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
                 const Float4 r0 = sc.rects[2 * idx], r1 = sc.rects[2 * idx + 1];
-                const int kaxis = (int)r1.y; const int ia = kaxis == 0 ? 1 : 0, ib = kaxis == 2 ? 1 : 2;
+                const int kaxis = (int)r1.y & 3; const int ia = kaxis == 0 ? 1 : 0, ib = kaxis == 2 ? 1 : 2;
                 p = ol + dl * t;                                            // aarect.rs:46
                 const float a = comp(p, ia), b = comp(p, ib);
                 hu = fdiv(a - r0.x, r0.y - r0.x); hv = fdiv(b - r0.z, r0.w - r0.z);   // :41-42

@@ -345,6 +345,8 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
     d.top_nodes = top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = top ? dn.n_top : 0u; d.n_records = c16 ? (uint32_t)n16.size() : dn.records();
     d.nodes16 = c16 ? 1u : 0u; for (int a = 0; a < 3; ++a) { d.grid_lo[a] = grid_lo[a]; d.grid_scale[a] = grid_scale[a]; }
+    d.n_prologue = (uint32_t)cs.prologue.size();
+    for (uint32_t k = 0; k < rtd::MAX_PROLOGUE; ++k) d.prologue[k] = k < cs.prologue.size() ? cs.prologue[k] : 0u;
     d.n_prim_kinds = (cs.sphere_meta.empty() ? 0u : 1u) + (cs.moving_meta.empty() ? 0u : 1u) + (cs.rect_meta.empty() ? 0u : 1u) +
                      (cs.tri_meta.empty() ? 0u : 1u) + (cs.media.empty() ? 0u : 1u);
     d.spheres = (const rtd::Float4*)s->spheres.p; d.sphere_meta = (const uint32_t*)s->sphere_meta.p; d.n_spheres = (uint32_t)cs.spheres.size();
@@ -582,7 +584,12 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         }
         stats->samples = valid_pixels * rd.spp;
         stats->segments = ctx->h_counters[rtk::CTR_SEGMENTS];
-        if (counting) {
+#ifdef RT_STAMPS
+        const bool copy_counts = true;    // k_extend's pass statistics travel in these slots (scripts/gpu_stamps.py)
+#else
+        const bool copy_counts = counting;
+#endif
+        if (copy_counts) {
             stats->node_tests = ctx->h_counters[rtk::CTR_NODE_TESTS];
             for (int k = 0; k < RT_N_PRIM_TYPES; ++k) stats->prim_tests[k] = ctx->h_counters[rtk::CTR_PRIM_TESTS + k];
         }

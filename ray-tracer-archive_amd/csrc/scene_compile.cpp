@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <map>
 
@@ -50,6 +51,8 @@ struct Compiler {
     CompiledScene& out;
     std::map<std::pair<long long, std::pair<long long, std::pair<long long, long long>>>, uint32_t> xform_cache;
     double pad_scale = 0.0;   // largest |coordinate| of the world's bounding box
+    bool cull_lists = true;   // HittableList members behind culling boxes (emit_list_culled); RT_LIST_CULL=0: every member probed by every ray, as the reference does
+    double park_cost = 6.0;   // what a stop of the walk at a leaf costs, in primitive tests (RT_LIST_PARK_COST)
     std::map<std::vector<long long>, uint32_t> wrap_cache;
 
     Compiler(const RtSceneDesc& desc, CompiledScene& o) : d(desc), out(o) {}
@@ -183,6 +186,7 @@ struct Compiler {
     uint32_t add_box_rects(const double* p, uint32_t meta) {
         const double x0 = p[0], y0 = p[1], z0 = p[2], x1 = p[3], y1 = p[4], z1 = p[5];
         const uint32_t first = add_rect(2, x0, x1, y0, y1, z1, meta);
+        out.rects.back().y += 4.f;   // "a box starts here": k_extend tests the six sides from this record and the next one's plane (kernels.hip)
         add_rect(2, x0, x1, y0, y1, z0, meta);
         add_rect(1, x0, x1, z0, z1, y1, meta);
         add_rect(1, x0, x1, z0, z1, y0, meta);
@@ -231,7 +235,8 @@ struct Compiler {
             out.moving.push_back(rtd::Float4{(float)p[3], (float)p[4], (float)p[5], (float)p[6]});
             out.moving.push_back(rtd::Float4{(float)p[7], 0.f, 0.f, 0.f});
             out.moving_meta.push_back(meta_for(h, ctx));
-            push_leaf_node(rtd::LT_MOVING, (uint32_t)out.moving_meta.size() - 1, 1);
+            if (to_prologue) out.prologue.push_back(rtd::make_leaf(rtd::LT_MOVING, (uint32_t)out.moving_meta.size() - 1, 1));
+            else push_leaf_node(rtd::LT_MOVING, (uint32_t)out.moving_meta.size() - 1, 1);
             break;
         case RT_HIT_XY_RECT: case RT_HIT_XZ_RECT: case RT_HIT_YZ_RECT: {
             const int kaxis = h.kind == RT_HIT_XY_RECT ? 2 : (h.kind == RT_HIT_XZ_RECT ? 1 : 0);
@@ -252,14 +257,148 @@ struct Compiler {
             break;
         }
         case RT_HIT_LIST:
-            for (int c = 0; c < h.n_children; ++c) {
-                if ((uint64_t)(h.first_child + c) >= d.n_children) { fail("children out of range"); return; }
-                emit(d.children[h.first_child + c], ctx, depth + 1);
-            }
+            for (int c = 0; c < h.n_children; ++c) if ((uint64_t)(h.first_child + c) >= d.n_children) { fail("children out of range"); return; }
+            if (cull_lists) emit_list_culled(h, ctx, depth);
+            else for (int c = 0; c < h.n_children; ++c) emit(d.children[h.first_child + c], ctx, depth + 1);
             break;
         case RT_HIT_BVH: emit_bvh(id, h, ctx, depth); break;
         case RT_HIT_CONSTANT_MEDIUM: emit_medium(id, h, ctx); break;
         default: fail("unknown hittable kind");
+        }
+    }
+
+    // ---- HittableList members behind culling boxes (not in the reference: HittableList::hit, hittable_list.rs:33-50, probes every member) ----
+    // A member whose box the ray misses cannot be hit, so skipping it changes no result; what it saves is the walk parking at the
+    // member's leaf (k_extend) and the member's own test. A box must hold for every ray time, so a subtree with a moving sphere outside a
+    // BVH (no time range to take the box over) gets none. Spheres count with |radius| (a hollow glass sphere has a negative one).
+    bool cull_bbox(int id, Box3& b, int depth = 0) {
+        if (id < 0 || (uint64_t)id >= d.n_hittables || depth > 128) return false;
+        const RtHittable* h = &d.hittables[id];
+        const double* p = h->p;
+        switch (h->kind) {
+        case RT_HIT_SPHERE: for (int i = 0; i < 3; ++i) { b.mn[i] = p[i] - std::fabs(p[3]); b.mx[i] = p[i] + std::fabs(p[3]); } return true;
+        case RT_HIT_MOVING_SPHERE: return false;
+        case RT_HIT_XY_RECT: case RT_HIT_XZ_RECT: case RT_HIT_YZ_RECT: case RT_HIT_TRIANGLE: case RT_HIT_BOX: {
+            const std::string keep = out.error; const bool r = bbox(id, 0.0, 1.0, b); out.error = keep; return r;
+        }
+        case RT_HIT_LIST: case RT_HIT_BVH: {
+            if (h->n_children <= 0) return false;
+            for (int c = 0; c < h->n_children; ++c) {
+                if ((uint64_t)(h->first_child + c) >= d.n_children) return false;
+                Box3 cb; if (!cull_bbox(d.children[h->first_child + c], cb, depth + 1)) return false;
+                b = c == 0 ? cb : surrounding(b, cb);
+            }
+            return true;
+        }
+        case RT_HIT_TRANSLATE: {
+            if (!cull_bbox(h->first_child, b, depth + 1)) return false;
+            for (int i = 0; i < 3; ++i) { b.mn[i] += p[i]; b.mx[i] += p[i]; }
+            return true;
+        }
+        case RT_HIT_ROTATE_Y: {
+            Box3 cb; if (!cull_bbox(h->first_child, cb, depth + 1)) return false;
+            const double radians = p[0] * PI / 180.0, s = std::sin(radians), c = std::cos(radians);
+            const double inf = std::numeric_limits<double>::infinity();
+            for (int i = 0; i < 3; ++i) { b.mn[i] = inf; b.mx[i] = -inf; }
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 2; ++k) {
+                const double x = i ? cb.mx[0] : cb.mn[0], y = j ? cb.mx[1] : cb.mn[1], z = k ? cb.mx[2] : cb.mn[2];
+                const double t[3] = {c * x + s * z, y, -s * x + c * z};
+                for (int a = 0; a < 3; ++a) { b.mn[a] = std::min(b.mn[a], t[a]); b.mx[a] = std::max(b.mx[a], t[a]); }
+            }
+            return true;
+        }
+        case RT_HIT_FLIP_FACE: case RT_HIT_CONSTANT_MEDIUM: return cull_bbox(h->first_child, b, depth + 1);
+        default: return false;
+        }
+    }
+    // leaf type a bare primitive lands in and the primitives it adds to it (0: not a bare primitive)
+    static uint32_t bare_kind(const RtHittable& h, uint32_t& count) {
+        count = 1;
+        switch (h.kind) {
+        case RT_HIT_SPHERE: return rtd::LT_SPHERE;
+        case RT_HIT_XY_RECT: case RT_HIT_XZ_RECT: case RT_HIT_YZ_RECT: return rtd::LT_RECT;
+        case RT_HIT_BOX: count = 6; return rtd::LT_RECT;
+        case RT_HIT_TRIANGLE: return rtd::LT_TRI;
+        default: return 0;
+        }
+    }
+    void emit_boxed(const std::vector<int>& ids, const Box3& box, const Chain& ctx, int depth) {
+        const uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.push_back(rtd::Node{});
+        out.n_box_nodes++;
+        for (int id : ids) emit(id, ctx, depth + 1);
+        finish_box_node(me, box);
+    }
+    // Members of the ROOT list that every ray meets — a moving sphere (no box without a time range) or a medium whose boundary holds
+    // everything else (the book-2 final scene's fog) — would stop every walk once each, as a primitive kind of their own. They go to
+    // the prologue instead: tested when a walk begins (k_extend), with all the lanes that begin together. HittableList::hit keeps the
+    // closest of its members' hits whatever their order (hittable_list.rs:40-47), so testing them first changes no hit.
+    bool prologue_member(const RtHittable& root, int c) {
+        const RtHittable& m = d.hittables[d.children[root.first_child + c]];
+        if (m.kind == RT_HIT_MOVING_SPHERE) return true;
+        if (m.kind != RT_HIT_CONSTANT_MEDIUM) return false;
+        Box3 mine;
+        if (!cull_bbox(d.children[root.first_child + c], mine)) return true;
+        for (int e = 0; e < root.n_children; ++e) {
+            Box3 b;
+            if (e == c || !cull_bbox(d.children[root.first_child + e], b)) continue;
+            for (int a = 0; a < 3; ++a) if (b.mn[a] < mine.mn[a] || b.mx[a] > mine.mx[a]) return false;
+        }
+        return true;
+    }
+    bool to_prologue = false;
+    void emit_list_culled(const RtHittable& h, const Chain& ctx, int depth) {
+        const int n = h.n_children;
+        const bool root = &h == &d.hittables[d.world] && ctx.identity && ctx.ops.empty();
+        std::vector<char> pro(n, 0);
+        if (root) {
+            size_t k = 0;
+            for (int c = 0; c < n; ++c) { const int id = d.children[h.first_child + c]; if (id >= 0 && (uint64_t)id < d.n_hittables && k < rtd::MAX_PROLOGUE && prologue_member(h, c)) { pro[c] = 1; ++k; } }
+            if (k == (size_t)n) std::fill(pro.begin(), pro.end(), 0);     // the walk needs a record to start at
+        }
+        int c = 0;
+        while (c < n && ok()) {
+            const int id = d.children[h.first_child + c];
+            const RtHittable* m = H(id); if (!m) return;
+            if (pro[c]) { to_prologue = true; emit(id, ctx, depth + 1); to_prologue = false; ++c; continue; }
+            uint32_t cnt0 = 0;
+            const uint32_t kind = bare_kind(*m, cnt0);
+            Box3 b0;
+            if (m->kind == RT_HIT_BVH || !cull_bbox(id, b0)) { emit(id, ctx, depth + 1); ++c; continue; }   // a BVH starts with its own box
+            if (kind == 0u) { emit_boxed({id}, b0, ctx, depth); ++c; continue; }
+            // a run of bare primitives of one leaf type: consecutive members share a leaf (one stop of the walk, `count` tests) or get
+            // leaves of their own (a stop each, but only for the rays that meet the smaller box). Cost of a leaf = chance of being met
+            // (~ half area of its box) x (park_cost + tests); the cheapest split of the run into consecutive groups, by dynamic programming.
+            std::vector<int> ids; std::vector<uint32_t> cnt; std::vector<Box3> box;
+            for (int e = c; e < n; ++e) {
+                const int eid = d.children[h.first_child + e];
+                if (eid < 0 || (uint64_t)eid >= d.n_hittables) break;
+                uint32_t k = 0; Box3 eb;
+                if (bare_kind(d.hittables[eid], k) != kind || !cull_bbox(eid, eb)) break;
+                ids.push_back(eid); cnt.push_back(k); box.push_back(eb);
+            }
+            const size_t r = ids.size();
+            std::vector<double> best(r + 1, std::numeric_limits<double>::infinity()); std::vector<size_t> from(r + 1, 0);
+            best[0] = 0.0;
+            for (size_t e = 1; e <= r; ++e) {
+                Box3 u = box[e - 1]; uint32_t tests = 0;
+                for (size_t s0 = e; s0-- > 0;) {
+                    u = surrounding(u, box[s0]); tests += cnt[s0];
+                    if (tests > rtd::LEAF_MAX_COUNT) break;
+                    const double cost = best[s0] + half_area(u) * (park_cost + (double)tests);
+                    if (cost < best[e]) { best[e] = cost; from[e] = s0; }
+                }
+            }
+            std::vector<size_t> cuts;
+            for (size_t e = r; e > 0; e = from[e]) cuts.push_back(e);
+            size_t s0 = 0;
+            for (size_t k = cuts.size(); k-- > 0;) {
+                const size_t e = cuts[k];
+                Box3 u = box[s0]; for (size_t i = s0 + 1; i < e; ++i) u = surrounding(u, box[i]);
+                emit_boxed(std::vector<int>(ids.begin() + s0, ids.begin() + e), u, ctx, depth);
+                s0 = e;
+            }
+            c += (int)r;
         }
     }
 
@@ -282,7 +421,8 @@ struct Compiler {
         m.meta = meta_for(h, none);
         m.medium_id = (uint32_t)id;
         out.media.push_back(m);
-        push_leaf_node(rtd::LT_MEDIUM, (uint32_t)out.media.size() - 1, 1);
+        if (to_prologue) out.prologue.push_back(rtd::make_leaf(rtd::LT_MEDIUM, (uint32_t)out.media.size() - 1, 1));
+        else push_leaf_node(rtd::LT_MEDIUM, (uint32_t)out.media.size() - 1, 1);
     }
 
     // ---- BVH ----
@@ -581,6 +721,15 @@ int compile_scene(const RtSceneDesc& desc, CompiledScene& out) {
     if ((desc.n_children && !desc.children) || (desc.n_materials && !desc.materials) || (desc.n_textures && !desc.textures) ||
         (desc.n_perlins && !desc.perlins) || (desc.n_images && !desc.images)) { out.error = "null array with non-zero count"; return RT_ERR_INVALID; }
     Compiler c(desc, out);
+    // Culling list members pays where the walks of a wave have already drifted apart (a BVH of some size in the scene): measured on the
+    // book-2 final scene k_extend 124 -> 108 ms. In a scene that is only a list (the Cornell boxes) every lane of a wave stops at the
+    // same leaves in the same order, a stop costs the wave the same with 64 lanes as with 20, and culling only breaks that step
+    // (Cornell 23 -> 33 ms, Cornell smoke 52 -> 60 ms): there the members stay as the reference has them.
+    uint64_t bvh_members = 0;
+    for (uint64_t i = 0; i < desc.n_hittables; ++i) if (desc.hittables[i].kind == RT_HIT_BVH && desc.hittables[i].n_children > 0) bvh_members += (uint64_t)desc.hittables[i].n_children;
+    c.cull_lists = bvh_members >= 32;
+    if (const char* e = getenv("RT_LIST_CULL")) c.cull_lists = e[0] == '2' ? true : (c.cull_lists && e[0] != '0');   // 0: never, 2: always (tests)
+    if (const char* e = getenv("RT_LIST_PARK_COST")) c.park_cost = std::max(0.0, std::atof(e));
     out.xforms.push_back(rtd::Xform{0.f, 1.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
     out.wraps.push_back(rtd::Wrap{});
     c.compile_materials();

@@ -22,6 +22,7 @@ struct CompiledScene {
     std::vector<rtd::PerlinTable> perlins;
     std::vector<rtd::Image> images;    std::vector<uint8_t> image_bytes;
     std::vector<rtd::Light> lights;
+    std::vector<uint32_t> prologue;                                          // leaf payloads of the root list's every-ray members (scene_compile.cpp: prologue_member)
     int background_mode = 0; float background[3] = {0, 0, 0};
     bool has_lights = false;
     // statistics

@@ -14,3 +14,6 @@ for which in sys.argv[1].split(","):
     scene = ctx.upload(hs.desc)
     img, st = ctx.render(scene, hs.camera(1.0), p.make_params(64, 64, 4, flags=2))
     print(which, {k: st[k] for k in st if k not in ("debug",)}, flush=True)
+    img, st = ctx.render(scene, hs.camera(1.0), p.make_params(400, 400, 64, flags=1))
+    seg = st["segments"]
+    print(which, "per segment: node tests %.2f" % (st["node_tests"] / seg), "prim tests [sphere moving rect tri medium enter]", [round(x / seg, 3) for x in st["prim_tests"]], "segments/sample %.2f" % (seg / st["samples"]), flush=True)

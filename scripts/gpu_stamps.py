@@ -11,7 +11,7 @@ if which == "c5":
     hs = p.HostScene("big_sah", 5, 1000000, 512); W, H, spp = 2048, 2048, 16
 elif which == "final":
     from PIL import Image
-    hs = p.HostScene("final", 1, image=np.asarray(Image.open("tests/golden/earthmap_rgb.png").convert("RGB"))); W, H, spp = 800, 800, 200
+    hs = p.HostScene("final", 1, image=np.asarray(Image.open("tests/golden/earthmap_rgb.png").convert("RGB"))); W, H, spp = 400, 400, 100
 elif which == "cornell":
     hs = p.HostScene("cornell", 0); W, H, spp = 600, 600, 500
 else:
@@ -26,3 +26,6 @@ d = st['debug']
 tot = d[3]
 print(which, "waves", d[4], "refill %.1f%% node %.1f%% prim %.1f%% other %.1f%%" % (100*d[0]/tot, 100*d[1]/tot, 100*d[2]/tot, 100*(tot-d[0]-d[1]-d[2])/tot), "cycles/wave %.0f" % (tot/d[4]),
       "extend_ms %.1f" % st['extend_ms'], "shade_ms %.1f" % st['shade_ms'], "iters", st['iterations'], "geom", st['debug'][6:8])
+if not (prm.flags & 1):
+    names = ["sphere", "moving", "rect", "tri", "medium"]
+    print("  prim passes/wave %.1f;" % (st["node_tests"] / d[4]), " ".join("%s: %.1f passes/wave, %.1f lanes/pass;" % (names[k], (v >> 40) / d[4], (v & ((1 << 40) - 1)) / max(1, v >> 40)) for k, v in enumerate(st["prim_tests"][:5]) if v), "segments/wave %.0f" % (st["segments"] / d[4]))

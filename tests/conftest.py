@@ -65,3 +65,22 @@ def record_metric(**kw):
             f.write(json.dumps(kw) + "\n")
     except OSError:
         pass
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def reference_shaped_lists():
+    """Scenes uploaded inside this block keep every HittableList member in front of every ray, as hittable_list.rs:33-50 does
+    (RT_LIST_CULL=0): the device's test counters then count what the reference's would. The default layout (culling boxes around
+    list members, every-ray members tested when a walk begins) gives the same picture with fewer tests."""
+    old = os.environ.get("RT_LIST_CULL")
+    os.environ["RT_LIST_CULL"] = "0"
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("RT_LIST_CULL", None)
+        else:
+            os.environ["RT_LIST_CULL"] = old
