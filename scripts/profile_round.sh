@@ -1,5 +1,5 @@
 # On the GPU box: the evidence committed under profiles/ for this round — rocprofv3 kernel-trace stats of bench.py, the PMC passes of the
-# bench workload (book-1, LDS-resident) and of the config-5 scene (compressed records in HBM), every BASELINE config, the three walks
+# bench workload (book-1, LDS-resident), of the config-5 scene (compressed records in HBM) and of configs 3 and 4 (book-2 final scene, Cornell box), every BASELINE config, the three walks
 # of config 5, and one plain bench line. Everything lands in gpurun_out/prof2/ (copied to profiles/ afterwards, on the CPU side,
 # by scripts/collect_profiles.py).
 cd /tmp && export TMPDIR=/tmp
@@ -11,6 +11,10 @@ bash scripts/pmc_passes.sh R2 > gpurun_out/prof2/pmc_book1_summary.txt 2>&1 || e
 echo "pmc book1 done" >> gpurun_out/prof2/progress.log
 bash scripts/pmc_c5.sh C5b 16 > gpurun_out/prof2/pmc_c5_summary.txt 2>&1 || exit 1
 echo "pmc c5 done" >> gpurun_out/prof2/progress.log
+bash scripts/pmc_scene.sh C3 final 800 800 200 || exit 1
+echo "pmc c3 done" >> gpurun_out/prof2/progress.log
+bash scripts/pmc_scene.sh C4 cornell 600 600 500 || exit 1
+echo "pmc c4 done" >> gpurun_out/prof2/progress.log
 timeout -k 10 400 python3 scripts/gpu_configs.py > gpurun_out/prof2/configs.log 2>&1 || exit 1
 cp gpurun_out/configs.json gpurun_out/prof2/configs.json
 timeout -k 10 300 python3 scripts/gpu_c5_top.py 32 > gpurun_out/prof2/c5_walks.log 2>&1 || exit 1
