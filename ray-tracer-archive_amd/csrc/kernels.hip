@@ -1485,6 +1485,13 @@ DEVI bool finish_sample(const RenderDev& rd, PathState& s, Rng& g, uint32_t& sam
 }
 
 template <uint32_t FEAT, bool COUNT>
+// The Cornell variant (rects, instance transforms, light sampling) at 6 waves per SIMD (79 VGPRs and 20 B of scratch instead of 87 and
+// none): k_shade 36.0 -> 32.2 ms on config 4. The full variant loses at every forced occupancy (5: 34.0 -> 36.7 ms on the book-2 final
+// scene, 6: 43.0), the sphere-only ones already run 8 waves.
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES (FEAT == (F_RECT | F_XFORM | F_LIGHTS) ? 6 : 4)
+#endif
+__attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, 8)))
 __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in, PoolDev out, RenderDev rd, const uint32_t* __restrict__ count_in_ptr,
                                                 uint32_t* __restrict__ count_out, uint32_t* __restrict__ next_work, uint32_t* __restrict__ head_to_zero,
                                                 unsigned long long* __restrict__ counters) {
