@@ -525,6 +525,8 @@ struct PathState {
     uint64_t rng;
 };
 constexpr int kShadeBatch = 16;   // DRAIN: lanes on DONE that trigger a shading pass
+// (more resident waves do not help the HBM walk: the config-5 variant forced to 7 waves per SIMD, 72 VGPRs, runs 198.2 ms against 197.2 at
+// 6 waves, and 210.5 ms at 8 with 44 B of scratch)
 template <int MODE, uint32_t FEAT, bool COUNT, uint32_t TPB, bool DRAIN>
 __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
                                                  uint32_t* __restrict__ head, uint32_t* __restrict__ count_out_to_zero,
