@@ -78,6 +78,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_REHEARSE_ON_ONE_GPU") == "1":
+        local_rank = 0     # rehearsal of the N > 1 control flow on a one-GPU box: every rank on device 0 (RCCL refuses that, so the staged gather runs)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -96,9 +98,14 @@ def main():
     assert stream.cuda_stream != 0
     ctx = pkg.Context(local_rank, stream.cuda_stream)
     gather_path = "single GPU"
+    staged_why = None
     if n_gpus > 1:
-        D.init_comm(ctx, rank, n_gpus, dist)             # rt_comm_init_rank: the data-path collective lives in the library
-        gather_path = "rt_render_gather: grouped ncclSend/ncclRecv to rank 0 (RCCL, called from csrc/rt_multi.cpp) + untile kernel"
+        ok, why = D.init_comm_guarded(ctx, rank, n_gpus, dist)   # rt_comm_init_rank + rt_comm_selftest: the data-path collective lives in the library
+        if ok:
+            gather_path = "rt_render_gather: grouped ncclSend/ncclRecv to rank 0 (RCCL, called from csrc/rt_multi.cpp) + untile kernel"
+        else:
+            staged_why = why
+            gather_path = "FALLBACK: shards staged through host memory over gloo, rt_untile_device on rank 0 (the library's RCCL exchange could not be set up: " + why + ")"
     hs = pkg.HostScene("book1", 1)
     scene = ctx.upload(hs.desc)
     W, H = (args.width, args.height) if args.width and args.height else image_size(n_gpus)
@@ -113,7 +120,10 @@ def main():
         if n_gpus == 1:
             stats_acc.append(ctx.render_device(scene, cam, base, frame1.data_ptr()))
             return frame1
-        frame, st = D.render_gathered(ctx, scene, cam, base, rank, A.RT_OUT_RGB_SUM_F32, device=dev)
+        if staged_why is None:
+            frame, st = D.render_gathered(ctx, scene, cam, base, rank, A.RT_OUT_RGB_SUM_F32, device=dev)
+        else:
+            frame, st = D.render_gathered_staged(ctx, scene, cam, base, rank, n_gpus, dist, A.RT_OUT_RGB_SUM_F32, device=dev)
         stats_acc.append(st)
         return frame
 
@@ -172,6 +182,8 @@ def main():
                     st = ctx.render_device(scene, scam, sprm, f.data_ptr())
                     ctx.resolve_device(f.data_ptr(), SW, SH, args.strong_spp, f8.data_ptr())
                     return st
+                if staged_why is not None:
+                    return D.render_gathered_staged(ctx, scene, scam, sprm, rank, n_gpus, dist, A.RT_OUT_RGB8, device=dev)[1]
                 return D.render_gathered(ctx, scene, scam, sprm, rank, A.RT_OUT_RGB8, device=dev)[1]
             sstep()
             barrier()

@@ -53,6 +53,60 @@ def render_gathered(ctx, scene, cam, base, rank, output_kind=A.RT_OUT_RGB_SUM_F3
     return frame, st
 
 
+def init_comm_guarded(ctx, rank, world, dist, timeout_s=180.0):
+    """init_comm + rt_comm_selftest on a helper thread with a deadline; every rank learns whether ALL ranks got their communicator.
+    Returns (ok, reason). A launcher uses it to fall back to render_gathered_staged instead of dying on a node whose RCCL set-up fails
+    (a hung set-up leaves the helper thread behind; the process still ends through the launcher)."""
+    import threading
+    import torch
+    err = []
+
+    def work():
+        try:
+            init_comm(ctx, rank, world, dist)
+            ctx.comm_selftest()
+        except Exception as e:      # noqa: BLE001 — reported, not swallowed
+            err.append(repr(e))
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    mine = "" if (not t.is_alive() and not err) else (err[0] if err else f"RCCL set-up did not finish within {timeout_s:.0f} s")
+    flag = torch.tensor([0.0 if mine else 1.0], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    reasons = [None] * world
+    dist.all_gather_object(reasons, mine)
+    ok = bool(flag.item() == 1.0)
+    return ok, "" if ok else "; ".join(f"rank {r}: {m}" for r, m in enumerate(reasons) if m)
+
+
+def render_gathered_staged(ctx, scene, cam, base, rank, world, dist, output_kind=A.RT_OUT_RGB_SUM_F32, device=None, tile_size=32):
+    """The same frame as render_gathered without RCCL: every rank renders its shard (rt_render_device), the shards travel through host
+    memory over `dist` (gloo), rank 0 puts the tiles in place on its device (rt_untile_device). RGB8: write_color per shard first
+    (rt_resolve_device on the shard buffer — it is per pixel, so tile order does not matter). Slow path for nodes where the library's
+    own exchange cannot be set up."""
+    import torch
+    prm = shard_params(base, rank, world, tile_size)
+    n = shard_floats(base, world, tile_size)
+    out = torch.zeros(n, dtype=torch.float32, device=device)
+    torch.cuda.current_stream(out.device).synchronize()
+    st = ctx.render_device(scene, cam, prm, out.data_ptr())
+    if output_kind == A.RT_OUT_RGB8:
+        out8 = torch.empty(n, dtype=torch.uint8, device=device)
+        torch.cuda.current_stream(out.device).synchronize()
+        ctx.resolve_device(out.data_ptr(), n // 3, 1, base.samples_per_pixel, out8.data_ptr())
+        out = out8
+    host = out.cpu()
+    parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+    dist.gather(host, gather_list=parts, dst=0)
+    if rank != 0:
+        return None, st
+    gathered = torch.cat(parts).to(device)
+    frame = torch.empty((base.height, base.width, 3), dtype=out.dtype, device=device)
+    torch.cuda.current_stream(frame.device).synchronize()
+    ctx.untile_device(shard_params(base, 0, world, tile_size), output_kind, gathered.data_ptr(), frame.data_ptr())
+    return frame, st
+
+
 def render_sharded(render_shard, base, rank, world, dist=None, tile_size=32, device=None):
     """Render this rank's tiles and gather all shards on rank 0 with torch.distributed.
 

@@ -95,3 +95,20 @@ def test_shard_resolve_and_device_untile(pkg, gpu, book1, world, tile):
     # and the host helpers agree with the device kernel
     assert np.array_equal(D.assemble(base, g32.cpu().numpy(), world, tile), ref)
     assert np.array_equal(pkg.untile_rgb8(prm0, g8.cpu().numpy().reshape(-1)), pkg.tonemap(ref, SPP))
+
+
+def test_two_ranks_on_one_gpu_fall_back_to_the_staged_gather():
+    """Two torchrun ranks on the one GPU of the test box: RCCL refuses a communicator with both ranks on one device, every rank
+    learns it (init_comm_guarded), and the staged gather — shards through host memory over gloo, untile kernel on rank 0 — gives the
+    single-GPU frame bit for bit (f32 sums and RGB8). This is the path bench.py takes on a node where the library's exchange cannot
+    be set up; the exchange itself between two real devices needs a multi-GPU node."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(root, "scripts", "gpu_staged_gather_check.py")], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("world 2")]
+    assert line and "staged f32 == single-GPU: True" in line[0] and "staged RGB8 == write_color(single-GPU): True" in line[0], r.stdout[-2000:]
