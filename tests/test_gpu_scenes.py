@@ -243,3 +243,50 @@ def test_time_survives_a_glass_bounce(pkg, orc, gpu):
             os.environ.pop("RT_DRAIN_AT", None)
         else:
             os.environ["RT_DRAIN_AT"] = old
+
+
+def test_list_culling_and_prologue_change_nothing_but_the_counters(pkg, orc, gpu):
+    """A root list with one of everything next to a BVH (so that the compiler culls its members, scene_compile.cpp emit_list_culled):
+    a hollow glass sphere (negative radius), a moving sphere (prologue), a fog that holds the whole scene (prologue), a small medium in
+    a rotated box, an instanced box, loose rects, triangles and a nested list. The culled layout, the layout forced for every scene
+    (RT_LIST_CULL=2) and the reference's layout (every member in front of every ray) render the same frame bit for bit; the oracle agrees
+    within the usual tolerances; the culled walk makes fewer primitive tests."""
+    import os
+    from conftest import reference_shaped_lists
+    rng = np.random.default_rng(11)
+    b = pkg.SceneBuilder(background=(0.55, 0.65, 0.9))
+    grey, red, glass, steel = b.lambertian((0.6, 0.6, 0.6)), b.lambertian((0.7, 0.2, 0.15)), b.dielectric(1.5), b.metal((0.8, 0.8, 0.9), 0.05)
+    cloud = [b.sphere((float(rng.uniform(-6, 6)), float(rng.uniform(0.2, 0.5)), float(rng.uniform(-6, 3))), float(rng.uniform(0.15, 0.35)),
+                      [grey, red, steel][i % 3]) for i in range(48)]
+    members = [
+        b.bvh(cloud),
+        b.sphere((0, -1000, 0), 1000, grey),
+        b.sphere((-2.5, 1.0, 0), 1.0, glass), b.sphere((-2.5, 1.0, 0), -0.9, glass),
+        b.moving_sphere((2.5, 1.0, -1), (2.5, 1.5, -1), 0.0, 1.0, 0.6, red),
+        b.constant_medium(b.sphere((0, 0, 0), 60, glass), 0.01, (1, 1, 1)),
+        b.constant_medium(b.translate(b.rotate_y(b.box((0, 0, 0), (1.2, 1.2, 1.2), grey), 25), (0.5, 0.0, 1.5)), 0.8, (0.1, 0.1, 0.1)),
+        b.translate(b.rotate_y(b.box((0, 0, 0), (1, 2, 1), steel), -18), (3.5, 0, -3)),
+        b.xz_rect(-1, 1, -4, -2, 3.5, b.diffuse_light((6, 6, 6))),
+        b.xy_rect(-6, -4, 0, 2, -5, red), b.yz_rect(0, 2, -5, -3, 6, grey),
+        b.triangle((-1, 0.01, 3), (1, 0.01, 3), (0, 1.5, 2.5), red), b.triangle((4, 0, 2), (5, 0, 2), (4.5, 1, 2.2), steel),
+        b.hittable_list([b.sphere((5, 0.5, 1), 0.5, steel), b.sphere((5, 1.4, 1), 0.4, red), b.box((-5, 0, 1), (-4, 1, 2), grey)]),
+    ]
+    desc = b.desc(b.hittable_list(members))
+    cam = pkg.camera_new((0, 3, 13), (0, 0.8, 0), (0, 1, 0), 40, 1.5, 0.0, 13.0, 0, 1)
+    W, H, SPP = 150, 100, 16
+    img, ref, st, ost = check(pkg, orc, gpu, desc, cam, W, H, SPP, bad_tol=0.03, seg_tol=3e-3)
+    prm = pkg.make_params(W, H, SPP, flags=pkg._abi.RT_FLAG_COUNTERS)
+    with reference_shaped_lists():
+        plain = gpu.upload(desc)
+    img_p, sp = gpu.render(plain, cam, prm)
+    os.environ["RT_LIST_CULL"] = "2"
+    try:
+        forced = gpu.upload(desc)
+    finally:
+        os.environ.pop("RT_LIST_CULL", None)
+    img_f, sf = gpu.render(forced, cam, prm)
+    assert np.array_equal(img, img_p) and np.array_equal(img, img_f)
+    assert st["segments"] == sp["segments"] == sf["segments"] and st["prim_tests"] == sf["prim_tests"]
+    assert abs(sp["prim_tests"][1] - sp["segments"]) <= 8 and abs(st["prim_tests"][1] - st["segments"]) <= 8     # the moving sphere: every segment, either way
+    assert sp["prim_tests"][4] >= 2 * sp["segments"] - 8 and st["prim_tests"][4] < 1.5 * st["segments"]            # both media for every ray / the small one culled
+    assert sum(st["prim_tests"][:5]) < 0.6 * sum(sp["prim_tests"][:5])
