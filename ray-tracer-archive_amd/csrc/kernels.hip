@@ -825,7 +825,14 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #pragma unroll
         for (int step = 0; step < kSteps; ++step) {
             const bool walk = pend == 0u;
+#ifdef RT_C16_LOAD_ALL
             const uint4 w = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(nodes) + node);
+#else
+            // only walking lanes load: a fully divergent 64-lane load occupies the CU's vector-memory pipe for about a cycle per lane, and
+            // on the config-5 scene 60 % of the lane-loads were parked or idle lanes re-reading a record they do not use
+            uint4 w = make_uint4(0u, 0xFFFFu, 0u, 0u);
+            if (walk) w = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(nodes) + node);
+#endif
             const uint32_t lx = w.x & 0xFFFFu, ly = w.x >> 16, lz = w.y & 0xFFFFu, hx = w.y >> 16, hy = w.z & 0xFFFFu, hz = w.z >> 16;
             const float t0x = fmaf((float)lx, qa.x, qb.x), t1x = fmaf((float)hx, qa.x, qb.x);
             const float t0y = fmaf((float)ly, qa.y, qb.y), t1y = fmaf((float)hy, qa.y, qb.y);

@@ -531,10 +531,15 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     };
     // The tail goes to the drain kernel: once at most `drain_at` paths are alive, ONE launch carries each of them to its end
     // (kernels.hip DRAIN). RT_FLAG_FUSED hands the whole render to it (a diagnostic: bit-identical frame, slower).
-    uint32_t drain_at = 1u << 18;   // measured on the bench workload: hand-over at 2^18 paths 103.2 ms, never 104.1, at 2^21 106.5, at 2^24 121
+    // LDS-resident scene, measured on the bench workload: hand-over at 2^18 paths 103.2 ms, never 104.1, at 2^21 106.5, at 2^24 121.
+    // Scene in HBM (config-5 stand-in, 2048^2 x 32): a k_extend launch does not get shorter than 1.5-2 ms however few rays it carries (the
+    // longest walk of the launch: hundreds of dependent loads), and 30 of the 50 iterations carry under 5 M paths: 2^18 211.5 ms,
+    // 2^20 188.6, 2^21 185.9, 2^22 193.4, 2^23 210.6, 2^24 246.9.
+    uint32_t drain_at = scene->in_lds ? (1u << 18) : (1u << 21);
     if (const char* e = getenv("RT_DRAIN_AT")) drain_at = (uint32_t)std::strtoul(e, nullptr, 10);
     if (prm->flags & RT_FLAG_FUSED) drain_at = 0xFFFFFFFFu;
     uint32_t launched = 0, drained = 0;
+    std::vector<uint32_t> iter_live;     // RT_DEBUG_ITER=1 (with RT_FLAG_TIMING): the host's bound of the largest queue at every iteration
     while (live > 0) {
         while (pending_head < pending.size() && hipEventQuery(pending[pending_head].ev) == hipSuccess) take(pending[pending_head++]);
         if (live == 0) break;
@@ -558,7 +563,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         if (timing) HIP_TRY(ctx, next_event(eb));
         HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, c_count[cur], c_count[1 - cur], c_next_work, c_head, c64, counting,
                                        ctx->stream));
-        if (timing) { HIP_TRY(ctx, next_event(ec)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); }
+        if (timing) { HIP_TRY(ctx, next_event(ec)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); iter_live.push_back(live); }
         cur = 1 - cur;
         const uint32_t ring = launched % kRing;
         HIP_TRY(ctx, hipMemcpy2DAsync(ctx->h_count + ring * rtk::kQueues, sizeof(uint32_t), c_count[cur], kLine, sizeof(uint32_t), rtk::kQueues, hipMemcpyDeviceToHost,
@@ -581,6 +586,15 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         for (const Span& s : spans) {
             float ms = 0.f; if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) continue;
             if (s.kind == 0) stats->extend_ms += ms; else if (s.kind == 1) stats->shade_ms += ms; else if (s.kind == 3) stats->drain_ms += ms; else stats->other_ms += ms;
+        }
+        if (const char* e = getenv("RT_DEBUG_ITER")) if (e[0] == '1' && timing) {
+            size_t it = 0;
+            for (size_t k = 0; k + 1 < spans.size(); ++k) {
+                if (spans[k].kind != 0 || spans[k + 1].kind != 1 || it >= iter_live.size()) continue;
+                float a = 0.f, b = 0.f; hipEventElapsedTime(&a, spans[k].a, spans[k].b); hipEventElapsedTime(&b, spans[k + 1].a, spans[k + 1].b);
+                std::fprintf(stderr, "iter %3zu  paths <= %10llu  k_extend %9.1f us  k_shade %8.1f us\n", it, (unsigned long long)iter_live[it] * rtk::kQueues, a * 1e3, b * 1e3);
+                ++it;
+            }
         }
         stats->samples = valid_pixels * rd.spp;
         stats->segments = ctx->h_counters[rtk::CTR_SEGMENTS];
