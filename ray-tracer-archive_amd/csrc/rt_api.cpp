@@ -223,14 +223,49 @@ static bool device_nodes(const std::vector<rtd::Node>& nodes, uint32_t max_top, 
 // Compressed layout (device_types.h Node16) for scenes that do not fit LDS. The grid spans the union of the finite boxes; a corner
 // is rounded outwards to the grid and moved one step further out, which covers the decode's rounding (t = q * (scale/d) + (lo - o)/d
 // carries ~1e-7 of the scene's extent in space, a grid step is 1.5e-5 of it). Returns false when the scene has no finite box.
-static bool device_nodes16(const std::vector<rtd::Node>& nodes, std::vector<rtd::Node16>& out, float grid_lo[3], float grid_scale[3]) {
+// ---- near-first record orders for the HBM walk ---------------------------------------------------------------------------------------
+// A threaded walk visits the children of a node in ONE fixed order. For a ray that runs against that order the far child comes first, its
+// hit does not shrink t_max for the near child, and the walk visits most of both subtrees. With 288 GB of HBM the remedy is space: the
+// record array once per direction OCTANT, each with the two children of every binary box node ordered near-first for that octant (the axis on
+// which the children's centres differ most decides). A walk starts in the array of its ray's octant; the arrays share the primitive
+// tables. Which child is visited first changes no closest hit (BVHNode::hit, bvh.rs:134-143, keeps the nearer of both whatever the order).
+static void octant_order(const std::vector<rtd::Node>& in, uint32_t oct, std::vector<rtd::Node>& out) {
+    const size_t n = in.size();
+    out.clear(); out.reserve(n);
+    auto boxed = [&](uint32_t i) { return std::isfinite(in[i].mn[0]) && std::isfinite(in[i].mx[0]) && std::isfinite(in[i].mn[1]) && std::isfinite(in[i].mx[1]) && std::isfinite(in[i].mn[2]) && std::isfinite(in[i].mx[2]); };
+    auto sub_end = [&](uint32_t i) { return (uint32_t)std::min<size_t>(std::max<size_t>(in[i].skip, (size_t)i + 1), n); };
+    std::vector<uint32_t> stack, kids;
+    for (uint32_t c = 0; c < n; c = sub_end(c)) kids.push_back(c);
+    for (size_t k = kids.size(); k-- > 0;) stack.push_back(kids[k]);
+    while (!stack.empty()) {
+        const uint32_t i = stack.back(); stack.pop_back();
+        const uint32_t pos = (uint32_t)out.size(), end = sub_end(i);
+        out.push_back(in[i]);
+        out[pos].skip = pos + (end - i);
+        if (in[i].leaf != 0u || end == i + 1) continue;
+        kids.clear();
+        for (uint32_t c = i + 1; c < end; c = sub_end(c)) kids.push_back(c);
+        if (kids.size() == 2 && boxed(kids[0]) && boxed(kids[1])) {
+            int axis = 0; double best = -1.0, ca[3], cb[3];
+            for (int a = 0; a < 3; ++a) {
+                ca[a] = 0.5 * ((double)in[kids[0]].mn[a] + in[kids[0]].mx[a]); cb[a] = 0.5 * ((double)in[kids[1]].mn[a] + in[kids[1]].mx[a]);
+                if (std::fabs(ca[a] - cb[a]) > best) { best = std::fabs(ca[a] - cb[a]); axis = a; }
+            }
+            const bool negative = ((oct >> axis) & 1u) != 0u;                  // the ray runs towards lower coordinates on that axis
+            if (ca[axis] != cb[axis] && (ca[axis] < cb[axis]) == negative) std::swap(kids[0], kids[1]);
+        }
+        for (size_t k = kids.size(); k-- > 0;) stack.push_back(kids[k]);
+    }
+}
+static bool device_nodes16(const std::vector<rtd::Node>& nodes, std::vector<rtd::Node16>& out, float grid_lo[3], float grid_scale[3], uint32_t link_base = 0u,
+                           bool keep_grid = false) {
     const size_t n = nodes.size();
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (const rtd::Node& nd : nodes) for (int a = 0; a < 3; ++a) {
         if (std::isfinite(nd.mn[a])) lo[a] = std::min(lo[a], (double)nd.mn[a]);
         if (std::isfinite(nd.mx[a])) hi[a] = std::max(hi[a], (double)nd.mx[a]);
     }
-    for (int a = 0; a < 3; ++a) {
+    for (int a = 0; a < 3 && !keep_grid; ++a) {
         if (!(hi[a] >= lo[a])) return false;
         const double pad = 1e-6 * (std::fabs(lo[a]) + std::fabs(hi[a])) + 1e-30;
         lo[a] -= pad; hi[a] += pad;
@@ -251,7 +286,7 @@ static bool device_nodes16(const std::vector<rtd::Node>& nodes, std::vector<rtd:
             r.lo[a] = (uint16_t)std::min(65535.0, std::max(0.0, ql));
             r.hi[a] = (uint16_t)std::min(65535.0, std::max(0.0, qh));
         }
-        r.link = nd.leaf != 0u ? (0x80000000u | nd.leaf) : (uint32_t)std::min<size_t>(nd.skip, n) * 16u;
+        r.link = nd.leaf != 0u ? (0x80000000u | nd.leaf) : link_base + (uint32_t)std::min<size_t>(nd.skip, n) * 16u;
         out[i] = r;
     }
     rtd::Node16 end{};                                                      // closing record: no box, "leaf" with the DONE payload (twice: a done lane reads one further)
@@ -286,7 +321,25 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     // RT_NODE16=0: keep 32-byte records (with the top of the tree in LDS) for a scene that does not fit LDS; default: 16-byte records
     bool want16 = !in_lds;
     if (const char* e = getenv("RT_NODE16")) want16 = want16 && e[0] != '0';
-    const bool c16 = want16 && device_nodes16(cs.nodes, n16, grid_lo, grid_scale);
+    bool c16 = want16 && device_nodes16(cs.nodes, n16, grid_lo, grid_scale);
+    // the record array once per direction octant (octant_order above), as long as 31-bit links reach; RT_OCTANT_ORDER=0: one array, the
+    // reference's order (left, then right) — what the oracle's visit counts are compared with
+    uint32_t oct_stride = 0u;
+    {
+        bool octants = c16 && 8ull * (cs.nodes.size() + 2) * 16ull < 0x7FFFFFF0ull;
+        if (const char* e = getenv("RT_OCTANT_ORDER")) octants = octants && e[0] != '0';
+        if (octants) {
+            const uint32_t stride = (uint32_t)((cs.nodes.size() + 2) * 16);
+            std::vector<rtd::Node16> all; all.reserve(8 * (cs.nodes.size() + 2));
+            std::vector<rtd::Node> ordered; std::vector<rtd::Node16> one;
+            for (uint32_t oct = 0; oct < 8 && octants; ++oct) {
+                octant_order(cs.nodes, oct, ordered);
+                octants = ordered.size() == cs.nodes.size() && device_nodes16(ordered, one, grid_lo, grid_scale, oct * stride, true);
+                all.insert(all.end(), one.begin(), one.end());
+            }
+            if (octants) { n16.swap(all); oct_stride = stride; }
+        }
+    }
     if (!c16 && !device_nodes(cs.nodes, in_lds ? 0u : max_top, dn)) { delete s; return set_err(ctx, RT_ERR_UNSUPPORTED, "scene: node array beyond 4 GB"); }
     const bool top = !c16 && dn.n_top != 0u;
     if (top) up(s->top_nodes, dn.top);
@@ -344,6 +397,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     rtk::SceneDev& d = s->dev;
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
     d.top_nodes = top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = top ? dn.n_top : 0u; d.n_records = c16 ? (uint32_t)n16.size() : dn.records();
+    d.oct_stride = oct_stride;
     d.nodes16 = c16 ? 1u : 0u; for (int a = 0; a < 3; ++a) { d.grid_lo[a] = grid_lo[a]; d.grid_scale[a] = grid_scale[a]; }
     d.n_prologue = (uint32_t)cs.prologue.size();
     for (uint32_t k = 0; k < rtd::MAX_PROLOGUE; ++k) d.prologue[k] = k < cs.prologue.size() ? cs.prologue[k] : 0u;

@@ -60,7 +60,7 @@ def check_config(pkg, gpu, name, tmp_path, earth, sah=False):
     hs = K.host_scene(pkg, name, tmp_path, sah=sah, earth=earth)
     scene = gpu.upload(hs.desc)
     with reference_shaped_lists():          # for the counters: list members as the reference walks them (conftest.py)
-        scene_counts = gpu.upload(hs.desc) if name in ("C3", "C4") else scene
+        scene_counts = gpu.upload(hs.desc) if name in ("C3", "C4", "C5") else scene
     cam = hs.camera(W / H)
     img, st = gpu.render(scene, cam, pkg.make_params(W, H, spp, max_depth=50, seed=cfg["seed"]))
     assert np.isfinite(img).all() and st["samples"] == W * H * spp
@@ -73,7 +73,15 @@ def check_config(pkg, gpu, name, tmp_path, earth, sah=False):
         ti, n_tiles = K.tile_index(name, crop)
         buf, ts = gpu.render(scene_counts, cam, pkg.make_params(W, H, spp, max_depth=50, seed=cfg["seed"], flags=A.RT_FLAG_COUNTERS, tile_size=K.TILE,
                                                          shard_index=ti, shard_count=n_tiles))
-        assert np.array_equal(buf.reshape(K.TILE, K.TILE, 3), a), (name, crop, "a tile rendered alone differs from the full frame")
+        if name == "C5":
+            # the reference's child order and the near-first orders (one record array per direction octant) find the same closest hits up
+            # to hits that tie within rounding (as for the SAH tree below); the tile of the production layout is the full frame's, bit for bit
+            differ = float((np.abs(buf.reshape(K.TILE, K.TILE, 3) - a).max(axis=2) > 0).mean())
+            assert differ < 2e-3, (name, crop, differ)
+            own, _ = gpu.render(scene, cam, pkg.make_params(W, H, spp, max_depth=50, seed=cfg["seed"], tile_size=K.TILE, shard_index=ti, shard_count=n_tiles))
+            assert np.array_equal(own.reshape(K.TILE, K.TILE, 3), a), (name, crop, "a tile rendered alone differs from the full frame")
+        else:
+            assert np.array_equal(buf.reshape(K.TILE, K.TILE, 3), a), (name, crop, "a tile rendered alone differs from the full frame")
         m["seg"] = abs(ts["segments"] - ctr[1]) / ctr[1]
         m["node"] = (ts["node_tests"] - ctr[2]) / max(1, ctr[2])
         prim_gpu, prim_orc = sum(ts["prim_tests"][:5]), sum(ctr[3:8])

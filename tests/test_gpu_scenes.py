@@ -199,6 +199,14 @@ def test_config5_million_spheres_and_mesh(pkg, orc, gpu):
     # (the culling test uses the running closest hit, so which of two hits ~1e-5 apart survives can depend on order)
     img2, _ = gpu.render(gpu.upload(ref_scene.desc), cam, prm)
     assert (np.abs(img - img2).max(axis=2) > 0).mean() < 2e-3
+    # one record array in the builder's child order against the default, one array per direction octant ordered near-first
+    # (rt_api.cpp octant_order): the same picture up to such ties, with far fewer visits
+    from conftest import reference_shaped_lists
+    with reference_shaped_lists():
+        one_order = gpu.upload(hs.desc)
+    img3, st3 = gpu.render(one_order, cam, prm)
+    assert (np.abs(img - img3).max(axis=2) > 0).mean() < 2e-3 and abs(st3["segments"] - st["segments"]) <= 1e-4 * st["segments"]
+    assert st["node_tests"] < 0.85 * st3["node_tests"] and sum(st["prim_tests"][:5]) < 0.85 * sum(st3["prim_tests"][:5])
 
 
 def test_imported_obj_mesh(pkg, orc, gpu, tmp_path):
