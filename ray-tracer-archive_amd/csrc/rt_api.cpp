@@ -585,11 +585,11 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     };
     // The tail goes to the drain kernel: once at most `drain_at` paths are alive, ONE launch carries each of them to its end
     // (kernels.hip DRAIN). RT_FLAG_FUSED hands the whole render to it (a diagnostic: bit-identical frame, slower).
-    // LDS-resident scene, measured on the bench workload: hand-over at 2^18 paths 103.2 ms, never 104.1, at 2^21 106.5, at 2^24 121.
-    // Scene in HBM (config-5 stand-in, 2048^2 x 32): a k_extend launch does not get shorter than 1.5-2 ms however few rays it carries (the
-    // longest walk of the launch: hundreds of dependent loads), and 30 of the 50 iterations carry under 5 M paths: 2^18 211.5 ms,
-    // 2^20 188.6, 2^21 185.9, 2^22 193.4, 2^23 210.6, 2^24 246.9.
-    uint32_t drain_at = scene->in_lds ? (1u << 18) : (1u << 21);
+    // Measured on the bench workload (LDS-resident scene): hand-over at 2^18 paths 103.2 ms, never 104.1, at 2^21 106.5, at 2^24 121. Scene in
+    // HBM (config-5 stand-in, 2048^2 x 32, near-first record orders): 2^18 126.0 ms, 2^20 126.2, 2^21 131.7, 2^22 143.4, 2^24 193.8. (With ONE
+    // record order a k_extend launch of that scene did not get shorter than 1.5-2 ms however few rays it carried — the longest far-first walk
+    // of the launch — and 2^21 was the best hand-over: 185.9 ms against 211.5 at 2^18.)
+    uint32_t drain_at = 1u << 18;
     if (const char* e = getenv("RT_DRAIN_AT")) drain_at = (uint32_t)std::strtoul(e, nullptr, 10);
     if (prm->flags & RT_FLAG_FUSED) drain_at = 0xFFFFFFFFu;
     uint32_t launched = 0, drained = 0;
