@@ -310,7 +310,8 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     RtScene* s = new RtScene();
     int r = RT_OK;
     auto up = [&](auto& buf, const auto& vec) { if (r == RT_OK) r = upload(ctx, buf, vec); };
-    const bool in_lds = lds_scene_bytes(cs) <= kLdsSceneBudget;
+    bool in_lds = lds_scene_bytes(cs) <= kLdsSceneBudget;
+    if (const char* e = getenv("RT_LDS_SCENE")) in_lds = in_lds && e[0] != '0';     // 0: walk a small scene from HBM too (experiments)
     // RT_TOP_NODES: records of the top of the tree kept in LDS for scenes that do not fit as a whole (0 = none)
     uint32_t max_top = 1024u;
     if (const char* e = getenv("RT_TOP_NODES")) max_top = (uint32_t)std::strtoul(e, nullptr, 10);
