@@ -23,6 +23,7 @@ struct SceneDev {
     uint32_t n_records;      // records of `nodes` in all: n_nodes + DONE + IDLE + one park twin per leaf (device_types.h)
     uint32_t nodes16;        // 1: `nodes` holds 16-byte compressed records (device_types.h Node16), corners on the grid below
     float grid_lo[3], grid_scale[3];
+    uint32_t oct_mask;       // direction signs that select an array (x = 1, y = 2, z = 4)
     uint32_t oct_stride;     // M_C16: bytes between the record arrays of two direction octants (rt_api.cpp octant_order); 0 = one array
     uint32_t n_prologue, prologue[rtd::MAX_PROLOGUE];   // moving spheres / media every ray meets: tested when a walk begins
     uint32_t n_prim_kinds;   // how many of {sphere, moving sphere, rect, triangle, medium} the scene holds

@@ -257,6 +257,30 @@ static void octant_order(const std::vector<rtd::Node>& in, uint32_t oct, std::ve
         for (size_t k = kids.size(); k-- > 0;) stack.push_back(kids[k]);
     }
 }
+// The axes worth an array of their own: bit a set when axis a separates the two children of at least 10 % of the binary box nodes. A
+// scene spread over a plane (config 5: a million spheres on the ground; y decides 6 % of its nodes) gets the arrays of 4 quadrants,
+// not 8 octants — half the cache footprint for the same visits (8 arrays 64.9 visits per segment, 1067 Msamples/s; x and z only 65.4, 1109).
+static uint32_t deciding_axes(const std::vector<rtd::Node>& in) {
+    const size_t n = in.size();
+    auto boxed = [&](size_t i) { for (int a = 0; a < 3; ++a) if (!std::isfinite(in[i].mn[a]) || !std::isfinite(in[i].mx[a])) return false; return true; };
+    auto sub_end = [&](size_t i) { return std::min<size_t>(std::max<size_t>(in[i].skip, i + 1), n); };
+    uint64_t count[3] = {0, 0, 0}, total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t end = sub_end(i);
+        if (in[i].leaf != 0u || end == i + 1) continue;
+        const size_t k0 = i + 1, k1 = sub_end(k0);
+        if (k1 >= end || sub_end(k1) != end || !boxed(k0) || !boxed(k1)) continue;     // exactly two children, both with a box
+        int axis = 0; double best = -1.0;
+        for (int a = 0; a < 3; ++a) {
+            const double dc = std::fabs(0.5 * ((double)in[k0].mn[a] + in[k0].mx[a]) - 0.5 * ((double)in[k1].mn[a] + in[k1].mx[a]));
+            if (dc > best) { best = dc; axis = a; }
+        }
+        count[axis]++; total++;
+    }
+    uint32_t mask = 0u;
+    for (int a = 0; a < 3; ++a) if (total != 0 && count[a] * 10u >= total) mask |= 1u << a;
+    return mask;
+}
 static bool device_nodes16(const std::vector<rtd::Node>& nodes, std::vector<rtd::Node16>& out, float grid_lo[3], float grid_scale[3], uint32_t link_base = 0u,
                            bool keep_grid = false) {
     const size_t n = nodes.size();
@@ -325,7 +349,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     bool c16 = want16 && device_nodes16(cs.nodes, n16, grid_lo, grid_scale);
     // the record array once per direction octant (octant_order above), as long as 31-bit links reach; RT_OCTANT_ORDER=0: one array, the
     // reference's order (left, then right) — what the oracle's visit counts are compared with
-    uint32_t oct_stride = 0u;
+    uint32_t oct_stride = 0u, oct_mask = 7u;
     {
         bool octants = c16 && 8ull * (cs.nodes.size() + 2) * 16ull < 0x7FFFFFF0ull;
         if (const char* e = getenv("RT_OCTANT_ORDER")) octants = octants && e[0] != '0';
@@ -333,7 +357,10 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
             const uint32_t stride = (uint32_t)((cs.nodes.size() + 2) * 16);
             std::vector<rtd::Node16> all; all.reserve(8 * (cs.nodes.size() + 2));
             std::vector<rtd::Node> ordered; std::vector<rtd::Node16> one;
+            oct_mask = deciding_axes(cs.nodes);
+            if (const char* e = getenv("RT_OCTANT_AXES")) oct_mask = (uint32_t)std::strtoul(e, nullptr, 10) & 7u;
             for (uint32_t oct = 0; oct < 8 && octants; ++oct) {
+                if ((oct & ~oct_mask) != 0u) { all.resize(all.size() + cs.nodes.size() + 2); continue; }      // never selected (kernels.hip go_root): left empty, never touched
                 octant_order(cs.nodes, oct, ordered);
                 octants = ordered.size() == cs.nodes.size() && device_nodes16(ordered, one, grid_lo, grid_scale, oct * stride, true);
                 all.insert(all.end(), one.begin(), one.end());
@@ -398,7 +425,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     rtk::SceneDev& d = s->dev;
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
     d.top_nodes = top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = top ? dn.n_top : 0u; d.n_records = c16 ? (uint32_t)n16.size() : dn.records();
-    d.oct_stride = oct_stride;
+    d.oct_stride = oct_stride; d.oct_mask = oct_mask;
     d.nodes16 = c16 ? 1u : 0u; for (int a = 0; a < 3; ++a) { d.grid_lo[a] = grid_lo[a]; d.grid_scale[a] = grid_scale[a]; }
     d.n_prologue = (uint32_t)cs.prologue.size();
     for (uint32_t k = 0; k < rtd::MAX_PROLOGUE; ++k) d.prologue[k] = k < cs.prologue.size() ? cs.prologue[k] : 0u;
