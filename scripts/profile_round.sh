@@ -19,5 +19,9 @@ timeout -k 10 400 python3 scripts/gpu_configs.py > gpurun_out/prof2/configs.log 
 cp gpurun_out/configs.json gpurun_out/prof2/configs.json
 timeout -k 10 300 python3 scripts/gpu_c5_top.py 32 > gpurun_out/prof2/c5_walks.log 2>&1 || exit 1
 echo "configs done" >> gpurun_out/prof2/progress.log
+# the PMC pass of the bench workload -> profiles/r02_pmc_book1.json of THIS copy, so that the bench line below carries the roofline of the
+# sources it runs (scripts/collect_profiles.py repeats the conversion on the CPU side, where git is, for the committed file)
+SEG=$(grep -o "segments [0-9]*" gpurun_out/pmcR21.log | tail -1 | cut -d" " -f2)
+python3 scripts/pmc_to_json.py R2 $SEG profiles/r02_pmc_book1.json "scripts/pmc_passes.sh R2 (on the GPU box)" > /dev/null || exit 1
 timeout -k 10 500 python3 bench.py > gpurun_out/prof2/bench.json 2> gpurun_out/prof2/bench.err || exit 1
 cat gpurun_out/prof2/bench.json
