@@ -901,7 +901,10 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         // (26 % VALU lane use before; k_extend 1039 -> 620 ms on that scene). With two or three kinds the extra passes cost
         // more than they save (Cornell +2 %, the 1 M-sphere + mesh scene +10 %), hence the scene-level switch.
         uint32_t serve = 0u;   // 0: every kind
-        if (FEAT != 0u && sc.n_prim_kinds >= 4u && do_prims) {
+#ifndef RT_SERVE_KINDS_MIN
+#define RT_SERVE_KINDS_MIN 4u
+#endif
+        if (FEAT != 0u && sc.n_prim_kinds >= RT_SERVE_KINDS_MIN && do_prims) {
             const uint32_t ty = pl >> 28;
             uint32_t best = 0u;
 #pragma unroll
