@@ -199,8 +199,10 @@ typedef struct RtStats {
     double other_ms;          /* generate / resolve kernels */
     uint64_t samples;         /* camera paths traced */
     uint64_t segments;        /* ray segments traced (world.hit calls, main.rs:74) */
-    uint64_t node_tests;      /* Aabb::hit evaluations (RT_FLAG_COUNTERS) */
-    uint64_t prim_tests[RT_N_PRIM_TYPES];
+    uint64_t node_tests;      /* box tests the device made (RT_FLAG_COUNTERS). They are the reference's Aabb::hit evaluations when the scene was
+                                 uploaded with RT_LIST_CULL=0 and RT_OCTANT_ORDER=0 in the environment; the default layouts cull HittableList
+                                 members behind boxes of their own and visit BVH children near-first: same hits, fewer tests */
+    uint64_t prim_tests[RT_N_PRIM_TYPES];   /* primitive hit() evaluations, by kind (a Box counts its six rects) */
     uint32_t iterations;      /* wavefront iterations */
     uint32_t extend_launches;
     uint32_t shade_launches;

@@ -348,7 +348,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     if (const char* e = getenv("RT_NODE16")) want16 = want16 && e[0] != '0';
     bool c16 = want16 && device_nodes16(cs.nodes, n16, grid_lo, grid_scale);
     // the record array once per direction octant (octant_order above), as long as 31-bit links reach; RT_OCTANT_ORDER=0: one array, the
-    // reference's order (left, then right) — what the oracle's visit counts are compared with
+    // reference's order (left, then right) — the order whose visit counts the tests compare with the CPU restatement's
     uint32_t oct_stride = 0u, oct_mask = 7u;
     {
         bool octants = c16 && 8ull * (cs.nodes.size() + 2) * 16ull < 0x7FFFFFF0ull;
