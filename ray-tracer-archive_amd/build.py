@@ -18,11 +18,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wal
 
 
 def source_hash():
-    """sha256 over the device-side sources: what a PMC profile under profiles/ is valid for (bench.py refuses a profile taken
-    from other kernels)."""
+    """sha256 over the sources that decide what the kernels execute per segment — the kernels, and the scene compiler and uploader that
+    lay the scene out for them: what a PMC profile under profiles/ is valid for (bench.py refuses a profile taken from other sources)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ["csrc/kernels.hip", "csrc/kernels.h", "csrc/device_types.h"]:
+    for f in ["csrc/kernels.hip", "csrc/kernels.h", "csrc/device_types.h", "csrc/scene_compile.cpp", "csrc/rt_api.cpp"]:
         h.update(open(os.path.join(HERE, f), "rb").read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()[:16]

@@ -51,6 +51,7 @@ struct Compiler {
     CompiledScene& out;
     std::map<std::pair<long long, std::pair<long long, std::pair<long long, long long>>>, uint32_t> xform_cache;
     double pad_scale = 0.0;   // largest |coordinate| of the world's bounding box
+    bool box_pair_members = false;
     bool cull_lists = true;   // HittableList members behind culling boxes (emit_list_culled); RT_LIST_CULL=0: every member probed by every ray, as the reference does
     double park_cost = 6.0;   // what a stop of the walk at a leaf costs, in primitive tests (RT_LIST_PARK_COST)
     std::map<std::vector<long long>, uint32_t> wrap_cache;
@@ -470,7 +471,7 @@ struct Compiler {
         out.nodes.push_back(rtd::Node{});
         out.n_box_nodes++;
         Box3 box = range_box(B, order, start, end);
-        auto make_leaf = [&]() { for (size_t i = start; i < end; ++i) emit(B.obj[order[i]], ctx, depth + 1); finish_box_node(me, box); return box; };
+        auto make_leaf = [&]() { for (size_t i = start; i < end; ++i) { if (n >= 2) emit_member(B, order[i], ctx, depth); else emit(B.obj[order[i]], ctx, depth + 1); } finish_box_node(me, box); return box; };
         if (n <= 2 || depth > 100) return make_leaf();
         constexpr int NB = 16;
         double cmn[3], cmx[3];
@@ -531,6 +532,17 @@ struct Compiler {
         return b;
     }
 
+    // A sphere that shares its BVH node with another object (the two members of a span-2 node, bvh.rs:99-107; the members of an SAH leaf)
+    // gets a box of its own in a scene small enough to be walked from LDS: the union box of two spheres is mostly empty, a sphere test
+    // costs four box tests, and a stop at a leaf costs more than either. Book-1: 6.0 -> 2.1 sphere tests and 41.7 -> 47.3 box tests per
+    // segment, k_extend 56.0 -> 52.1 ms, same frame bit for bit. Boxes and rects are their own bounding boxes already (measured: boxing them
+    // too costs the book-2 final scene 4 %); in a scene walked from HBM a box record is a load like the sphere record it would spare.
+    void emit_member(const Build& B, int k, const Chain& ctx, int depth) {
+        const RtHittable* m = H(B.obj[k]);
+        if (box_pair_members && m && (m->kind == RT_HIT_SPHERE || m->kind == RT_HIT_MOVING_SPHERE)) emit_boxed({B.obj[k]}, B.box[k], ctx, depth);
+        else emit(B.obj[k], ctx, depth + 1);
+    }
+
     // BVHNode::construct (bvh.rs:77-130) on the sub-range [start, end)
     Box3 build_range(Build& B, std::vector<int>& order, size_t start, size_t end, const Chain& ctx, int depth) {
         B.axis_state += GAMMA;
@@ -547,8 +559,8 @@ struct Compiler {
             const int a = order[start], b = order[start + 1];
             const bool less = B.key[axis][a] < B.key[axis][b];   // box_compare: strictly less, else "greater" (bvh.rs:24-31)
             const int l = less ? a : b, r = less ? b : a;
-            emit(B.obj[l], ctx, depth + 1);
-            emit(B.obj[r], ctx, depth + 1);
+            emit_member(B, l, ctx, depth);
+            emit_member(B, r, ctx, depth);
             box = surrounding(B.box[l], B.box[r]);
         } else {
             const std::vector<double>& key = B.key[axis];
@@ -771,6 +783,8 @@ int compile_scene(const RtSceneDesc& desc, CompiledScene& out) {
     for (uint64_t i = 0; i < desc.n_hittables; ++i) if (desc.hittables[i].kind == RT_HIT_BVH && desc.hittables[i].n_children > 0) bvh_members += (uint64_t)desc.hittables[i].n_children;
     c.cull_lists = bvh_members >= 32;
     if (const char* e = getenv("RT_LIST_CULL")) c.cull_lists = e[0] == '2' ? true : (c.cull_lists && e[0] != '0');   // 0: never, 2: always (tests)
+    c.box_pair_members = desc.n_hittables < 8192;      // scenes of that size are LDS-resident (rt_api.cpp: 144 KB of records and spheres)
+    if (const char* e = getenv("RT_PAIR_BOXES")) c.box_pair_members = e[0] == '2' ? true : (c.box_pair_members && e[0] != '0');   // 0: never, 2: always
     if (const char* e = getenv("RT_LIST_PARK_COST")) c.park_cost = std::max(0.0, std::atof(e));
     out.xforms.push_back(rtd::Xform{0.f, 1.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
     out.wraps.push_back(rtd::Wrap{});

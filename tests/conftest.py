@@ -77,7 +77,8 @@ def reference_shaped_lists():
     list members, every-ray members tested when a walk begins) gives the same picture with fewer tests."""
     # ... and RT_OCTANT_ORDER=0: one record array in the reference's child order (left, then right, bvh.rs:134-143) instead of one array
     # per direction octant ordered near-first (scenes in HBM)
-    names = ("RT_LIST_CULL", "RT_OCTANT_ORDER")
+    # ... and RT_PAIR_BOXES=0: the two members of a span-2 BVH node without boxes of their own (bvh.rs:99-107 tests both objects directly)
+    names = ("RT_LIST_CULL", "RT_OCTANT_ORDER", "RT_PAIR_BOXES")
     old = {k: os.environ.get(k) for k in names}
     for k in names:
         os.environ[k] = "0"

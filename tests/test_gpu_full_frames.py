@@ -60,7 +60,7 @@ def check_config(pkg, gpu, name, tmp_path, earth, sah=False):
     hs = K.host_scene(pkg, name, tmp_path, sah=sah, earth=earth)
     scene = gpu.upload(hs.desc)
     with reference_shaped_lists():          # for the counters: list members as the reference walks them (conftest.py)
-        scene_counts = gpu.upload(hs.desc) if name in ("C3", "C4", "C5") else scene
+        scene_counts = gpu.upload(hs.desc)
     cam = hs.camera(W / H)
     img, st = gpu.render(scene, cam, pkg.make_params(W, H, spp, max_depth=50, seed=cfg["seed"]))
     assert np.isfinite(img).all() and st["samples"] == W * H * spp
