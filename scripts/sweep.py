@@ -17,7 +17,7 @@ VARIANTS = {
     "stamps": ["RT_STAMPS=1"],
     "sk9": ["RT_SERVE_KINDS_MIN=9u"], "sk9b32": ["RT_SERVE_KINDS_MIN=9u", "RT_LEAF_BATCH=32"], "sk9b16": ["RT_SERVE_KINDS_MIN=9u", "RT_LEAF_BATCH=16"],
     "c16all": ["RT_C16_LOAD_ALL=1"],
-    "sw5": ["RT_SHADE_WAVES=5"], "sw6": ["RT_SHADE_WAVES=6"], "sw8": ["RT_SHADE_WAVES=8"],
+    "sw7": ["RT_SHADE_WAVES=7"], "sw5": ["RT_SHADE_WAVES=5"], "sw6": ["RT_SHADE_WAVES=6"], "sw8": ["RT_SHADE_WAVES=8"],
     "sb16": ["RT_SERVE_BEST=16"], "sb24": ["RT_SERVE_BEST=24"], "sb32": ["RT_SERVE_BEST=32"], "sb40": ["RT_SERVE_BEST=40"], "sb48": ["RT_SERVE_BEST=48"],
     "b32r24": ["RT_LEAF_BATCH=32"], "b40": ["RT_LEAF_BATCH=40"], "b48": ["RT_LEAF_BATCH=48"],
     "r1": ["RT_REFILL_MIN=1"],

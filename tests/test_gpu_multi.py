@@ -106,8 +106,12 @@ def test_two_ranks_on_one_gpu_fall_back_to_the_staged_gather():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+    with socket.socket() as sk:                      # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(root, "scripts", "gpu_staged_gather_check.py")], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("world 2")]
