@@ -160,6 +160,14 @@ def main():
             gather_path = "FALLBACK: shards staged through host memory over gloo, rt_untile_device on rank 0 (the library's RCCL exchange could not be set up: " + why + ")"
     hs = pkg.HostScene("book1", 1)
     scene = ctx.upload(hs.desc)
+    if n_gpus > 1 and staged_why is None:
+        # the first exchange between the devices of this node: a small frame, compared on rank 0 with its own render of it
+        ok, why = D.trial_gather(ctx, scene, hs.camera(160 / 96), rank, n_gpus, dist, dev)
+        if ok:
+            gather_path += "; verified on a 160x96 frame against rank 0's own render, bit for bit"
+        else:
+            staged_why = why
+            gather_path = "FALLBACK: shards staged through host memory over gloo, rt_untile_device on rank 0 (the library's RCCL exchange failed its trial: " + why + ")"
     W, H = (args.width, args.height) if args.width and args.height else image_size(n_gpus)
     cam = hs.camera(W / H)
     base = pkg.make_params(W, H, args.spp, max_depth=50, seed=1, flags=A.RT_FLAG_TIMING, pool_slots=args.pool_slots)

@@ -79,6 +79,41 @@ def init_comm_guarded(ctx, rank, world, dist, timeout_s=180.0):
     return ok, "" if ok else "; ".join(f"rank {r}: {m}" for r, m in enumerate(reasons) if m)
 
 
+def trial_gather(ctx, scene, cam, rank, world, dist, device, width=160, height=96, spp=2, timeout_s=120.0):
+    """One small rt_render_gather through the freshly made communicator, on a helper thread with a deadline; rank 0 renders the same
+    frame alone and compares bit for bit (the picture does not depend on the number of shards). Every rank learns the outcome. This is
+    the first time the exchange runs between the devices of THIS node, so a launcher calls it before it trusts rt_render_gather."""
+    import threading
+    import torch
+    base = api.make_params(width, height, spp, max_depth=50, seed=1)
+    box = {}
+
+    def work():
+        try:
+            frame, _ = render_gathered(ctx, scene, cam, base, rank, A.RT_OUT_RGB_SUM_F32, device=device)
+            box["frame"] = frame
+        except Exception as e:      # noqa: BLE001
+            box["err"] = repr(e)
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    mine = ""
+    if t.is_alive():
+        mine = f"rt_render_gather did not return within {timeout_s:.0f} s"
+    elif "err" in box:
+        mine = box["err"]
+    elif rank == 0:
+        own, _ = ctx.render(scene, cam, base)
+        if not np.array_equal(box["frame"].cpu().numpy(), own):
+            mine = "gathered frame differs from rank 0's own render of the same frame"
+    flag = torch.tensor([0.0 if mine else 1.0], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    reasons = [None] * world
+    dist.all_gather_object(reasons, mine)
+    ok = bool(flag.item() == 1.0)
+    return ok, "" if ok else "; ".join(f"rank {r}: {m}" for r, m in enumerate(reasons) if m)
+
+
 def render_gathered_staged(ctx, scene, cam, base, rank, world, dist, output_kind=A.RT_OUT_RGB_SUM_F32, device=None, tile_size=32):
     """The same frame as render_gathered without RCCL: every rank renders its shard (rt_render_device), the shards travel through host
     memory over `dist` (gloo), rank 0 puts the tiles in place on its device (rt_untile_device). RGB8: write_color per shard first
