@@ -329,6 +329,12 @@ def main():
                             "measured_hbm_gbs": round(seg * pmc["bytes_per_segment"] / ext_s / 1e9, 1) if pmc and ext_s > 0 else None,
                             "measured_over_hbm_peak": round(seg * pmc["bytes_per_segment"] / ext_s / 1e9 / HBM_PEAK_GBS, 4) if pmc and ext_s > 0 else None,
                             "note": "the 24 KB scene is LDS-resident: HBM sees the ray records only; the HBM roofline applies to config 5 (profiles/r02_pmc_c5.json)"}
+        # the second kernel of a step, k_shade, is the HBM-side one: PMC bytes per segment x this run's segments / its kernel time
+        if pmc is not None and shade_ms > 0 and "k_shade" in tj["kernels"]:
+            sb = tj["kernels"]["k_shade"]["bytes_per_segment"]
+            sg = seg * sb / (shade_ms * 1e-3) / 1e9
+            roof["k_shade"] = {"bound": "hbm", "bytes_per_segment": sb, "achieved": round(sg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sg / HBM_PEAK_GBS, 4),
+                               "share_of_step": round(shade_ms / max(1e-9, ext_ms + shade_ms + other_ms), 3)}
         out["roofline"] = roof
     except Exception as e:   # the contract line must survive a failure in the extras
         out["roofline"] = {"bound": "valu", "error": repr(e)}
