@@ -47,6 +47,7 @@ struct SceneDev {
     // sphere data (book-3 Cornell tests its 12 rects on every segment)
     const rtd::Float4* ext_blob; uint32_t ext_blob_bytes; uint32_t eb_rects, eb_moving, eb_xforms, eb_media;
     uint32_t eb_rect_stride;   // 32: the rect table as it is (sc.rects is redirected too); 24: without the two padding words, where only that fits
+    uint32_t sb_perlin_only;   // 1: the blob holds the Perlin tables alone (a scene whose other tables are too big to stage: book-2 final)
     uint32_t sb_spheres, sb_sphere_meta, sb_rects, sb_rect_meta, sb_moving, sb_moving_meta, sb_mat_a, sb_mat_b, sb_xforms, sb_wraps, sb_lights, sb_textures;   // byte offsets
 };
 

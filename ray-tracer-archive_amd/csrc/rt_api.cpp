@@ -378,7 +378,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
     // k_shade's small tables as one blob for LDS staging (kernels.h SceneDev::shade_blob): only when it is small. RT_SHADE_LDS=0 turns it off.
     std::vector<unsigned char> blob;
-    uint32_t sb[12] = {0};
+    uint32_t sb[12] = {0}, perlin_only = 0u;
     {
         auto put = [&](const void* p, size_t bytes) { const uint32_t at = (uint32_t)blob.size(); blob.resize((blob.size() + bytes + 15) & ~(size_t)15, 0); if (bytes) std::memcpy(blob.data() + at, p, bytes); return at; };
         sb[0] = put(cs.spheres.data(), cs.spheres.size() * 16); sb[1] = put(cs.sphere_meta.data(), cs.sphere_meta.size() * 4);
@@ -391,6 +391,13 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
         bool on = blob.size() <= 8 * 1024;
         if (const char* e = getenv("RT_SHADE_LDS")) on = on && e[0] != '0';
         if (!on) blob.clear();
+        // a scene with noise textures whose other tables are too big to stage: the Perlin tables alone (7 KB each). A turbulence is a chain of
+        // 7 x 8 x 4 dependent look-ups, and a wave waits for the one lane that makes it (RT_SHADE_PERLIN_LDS=0 turns this off)
+        if (blob.empty() && !cs.perlins.empty() && cs.perlins.size() * sizeof(rtd::PerlinTable) <= 16 * 1024) {
+            bool pon = true;
+            if (const char* e = getenv("RT_SHADE_PERLIN_LDS")) pon = e[0] != '0';
+            if (pon) { put(cs.perlins.data(), cs.perlins.size() * sizeof(rtd::PerlinTable)); perlin_only = 1u; }
+        }
     }
     if (!blob.empty()) up(s->shade_blob, blob);
     // k_extend's primitive pass tables for LDS-resident scenes (kernels.h SceneDev::ext_blob): small ones only, inside the LDS budget
@@ -444,6 +451,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     d.sb_spheres = sb[0]; d.sb_sphere_meta = sb[1]; d.sb_rects = sb[2]; d.sb_rect_meta = sb[3]; d.sb_moving = sb[4]; d.sb_moving_meta = sb[5];
     d.ext_blob = eblob.empty() ? nullptr : (const rtd::Float4*)s->ext_blob.p; d.ext_blob_bytes = (uint32_t)eblob.size();
     d.eb_rect_stride = eb_rect_stride; d.eb_rects = eb[0]; d.eb_moving = eb[1]; d.eb_xforms = eb[2]; d.eb_media = eb[3];
+    d.sb_perlin_only = perlin_only;
     d.sb_mat_a = sb[6]; d.sb_mat_b = sb[7]; d.sb_xforms = sb[8]; d.sb_wraps = sb[9]; d.sb_lights = sb[10]; d.sb_textures = sb[11];
     const uint32_t f = scene_features(cs);
     s->features = f;
