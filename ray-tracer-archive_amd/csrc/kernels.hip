@@ -1522,8 +1522,14 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const char* t = reinterpret_cast<const char*>(s_tables);
-        if (sc.sb_perlin_only != 0u) sc.perlins = reinterpret_cast<const rtd::PerlinTable*>(t);
-        else {
+        if (sc.sb_perlin_only != 0u) {       // the Perlin tables first, then the tables that do not grow with the primitive count
+            sc.perlins = reinterpret_cast<const rtd::PerlinTable*>(t);
+            if (sc.sb_perlin_only == 1u) {
+            sc.mat_a = reinterpret_cast<const Float4*>(t + sc.sb_mat_a); sc.mat_b = reinterpret_cast<const uint32_t*>(t + sc.sb_mat_b);
+            sc.xforms = reinterpret_cast<const rtd::Xform*>(t + sc.sb_xforms); sc.wraps = reinterpret_cast<const rtd::Wrap*>(t + sc.sb_wraps);
+            sc.lights = reinterpret_cast<const rtd::Light*>(t + sc.sb_lights); sc.textures = reinterpret_cast<const rtd::Texture*>(t + sc.sb_textures);
+            }
+        } else {
         sc.spheres = reinterpret_cast<const Float4*>(t + sc.sb_spheres); sc.sphere_meta = reinterpret_cast<const uint32_t*>(t + sc.sb_sphere_meta);
         sc.rects = reinterpret_cast<const Float4*>(t + sc.sb_rects); sc.rect_meta = reinterpret_cast<const uint32_t*>(t + sc.sb_rect_meta);
         sc.moving = reinterpret_cast<const Float4*>(t + sc.sb_moving); sc.moving_meta = reinterpret_cast<const uint32_t*>(t + sc.sb_moving_meta);

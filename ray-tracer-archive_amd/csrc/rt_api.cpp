@@ -396,7 +396,17 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
         if (blob.empty() && !cs.perlins.empty() && cs.perlins.size() * sizeof(rtd::PerlinTable) <= 16 * 1024) {
             bool pon = true;
             if (const char* e = getenv("RT_SHADE_PERLIN_LDS")) pon = e[0] != '0';
-            if (pon) { put(cs.perlins.data(), cs.perlins.size() * sizeof(rtd::PerlinTable)); perlin_only = 1u; }
+            if (pon) {
+                put(cs.perlins.data(), cs.perlins.size() * sizeof(rtd::PerlinTable)); perlin_only = 1u;
+                // ... and the tables that do not grow with the primitive count, if they are small: material, texture, transform, wrapper, light
+                const size_t small = cs.mat_a.size() * 20 + cs.xforms.size() * sizeof(rtd::Xform) + cs.wraps.size() * sizeof(rtd::Wrap) + cs.lights.size() * sizeof(rtd::Light) +
+                                     cs.textures.size() * sizeof(rtd::Texture);
+                if (small <= 4 * 1024) {
+                    sb[6] = put(cs.mat_a.data(), cs.mat_a.size() * 16); sb[7] = put(cs.mat_b.data(), cs.mat_b.size() * 4);
+                    sb[8] = put(cs.xforms.data(), cs.xforms.size() * sizeof(rtd::Xform)); sb[9] = put(cs.wraps.data(), cs.wraps.size() * sizeof(rtd::Wrap));
+                    sb[10] = put(cs.lights.data(), cs.lights.size() * sizeof(rtd::Light)); sb[11] = put(cs.textures.data(), cs.textures.size() * sizeof(rtd::Texture));
+                } else perlin_only = 2u;
+            }
         }
     }
     if (!blob.empty()) up(s->shade_blob, blob);
