@@ -298,3 +298,62 @@ def test_list_culling_and_prologue_change_nothing_but_the_counters(pkg, orc, gpu
     assert abs(sp["prim_tests"][1] - sp["segments"]) <= 8 and abs(st["prim_tests"][1] - st["segments"]) <= 8     # the moving sphere: every segment, either way
     assert sp["prim_tests"][4] >= 2 * sp["segments"] - 8 and st["prim_tests"][4] < 1.5 * st["segments"]            # both media for every ray / the small one culled
     assert sum(st["prim_tests"][:5]) < 0.6 * sum(sp["prim_tests"][:5])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_graphs_render_the_same_under_every_layout(pkg, gpu, seed):
+    """Random object graphs — lists in lists, BVHs in lists, instanced boxes and spheres, media with sphere and box boundaries, moving and
+    hollow spheres, loose rects and triangles, in random order — rendered under the layouts the uploader can choose: list members culled
+    and every-ray members in the prologue (forced), pair members boxed (forced), versus the reference's shape. Same frame, bit for bit."""
+    import os
+    from conftest import reference_shaped_lists
+    rng = np.random.default_rng(100 + seed)
+    b = pkg.SceneBuilder(background=(0.6, 0.7, 0.95))
+    mats = [b.lambertian(tuple(rng.uniform(0.2, 0.8, 3))) for _ in range(4)] + [b.metal((0.8, 0.8, 0.8), float(rng.uniform(0, 0.3))), b.dielectric(1.5)]
+    U = lambda lo, hi, n=None: rng.uniform(lo, hi, n)
+
+    def rand_prim():
+        k = int(rng.integers(0, 7))
+        c = U(-5, 5, 3); c[1] = abs(c[1]) * 0.4
+        m = mats[int(rng.integers(0, len(mats)))]
+        if k == 0: return b.sphere(tuple(c), float(U(0.2, 0.8)), m)
+        if k == 1: return b.moving_sphere(tuple(c), tuple(c + (0, float(U(0.1, 0.6)), 0)), 0.0, 1.0, float(U(0.2, 0.5)), mats[int(rng.integers(0, 4))])
+        if k == 2: return b.box(tuple(c), tuple(c + U(0.3, 1.5, 3)), m)
+        if k == 3: return b.translate(b.rotate_y(b.box((0, 0, 0), tuple(U(0.4, 1.4, 3)), m), float(U(-60, 60))), tuple(c))
+        if k == 4: return b.xz_rect(c[0], c[0] + 1.5, c[2], c[2] + 1.5, float(U(0.05, 2.5)), m)
+        if k == 5: return b.triangle(tuple(c), tuple(c + (1, 0, 0.2)), tuple(c + (0.3, 1, 0)), m)
+        return b.translate(b.sphere((0, 0, 0), float(U(0.2, 0.6)), m), tuple(c))
+
+    def rand_group(depth):
+        n = int(rng.integers(2, 7))
+        kids = []
+        for _ in range(n):
+            r = rng.random()
+            if depth < 2 and r < 0.2: kids.append(rand_group(depth + 1))
+            elif r < 0.3: kids.append(b.constant_medium(b.sphere(tuple(U(-4, 4, 3)), float(U(0.5, 1.2)), mats[5]), float(U(0.2, 1.5)), tuple(U(0.1, 0.9, 3))))
+            elif r < 0.36: kids.append(b.constant_medium(b.translate(b.box((0, 0, 0), (1, 1, 1), mats[0]), tuple(U(-4, 4, 3))), float(U(0.3, 1.0)), (0.9, 0.9, 0.9)))
+            else: kids.append(rand_prim())
+        return b.bvh(kids, 0.0, 1.0) if rng.random() < 0.4 else b.hittable_list(kids)
+
+    top = [b.sphere((0, -1000, 0), 1000, mats[0]), b.bvh([b.sphere(tuple(U(-6, 6, 3) * (1, 0.1, 1) + (0, 0.3, 0)), 0.25, mats[int(rng.integers(0, 6))]) for _ in range(40)]),
+           b.sphere((2, 1, 0), 1.0, mats[5]), b.sphere((2, 1, 0), -0.85, mats[5])]
+    top += [rand_group(0) for _ in range(3)] + [rand_prim() for _ in range(4)]
+    if seed % 2: top.append(b.constant_medium(b.sphere((0, 0, 0), 80, mats[5]), 0.005, (1, 1, 1)))
+    order = rng.permutation(len(top))
+    desc = b.desc(b.hittable_list([top[i] for i in order]))
+    cam = pkg.camera_new((0, 3, 14), (0, 0.8, 0), (0, 1, 0), 40, 1.5, 0.05, 14.0, 0, 1)
+    prm = pkg.make_params(96, 64, 4, seed=seed, flags=pkg._abi.RT_FLAG_COUNTERS)
+    with reference_shaped_lists():
+        plain = gpu.upload(desc)
+    ref, sr = gpu.render(plain, cam, prm)
+    assert np.isfinite(ref).all() and sr["segments"] > 96 * 64 * 4
+    os.environ["RT_LIST_CULL"] = "2"; os.environ["RT_PAIR_BOXES"] = "2"
+    try:
+        forced = gpu.upload(desc)
+    finally:
+        os.environ.pop("RT_LIST_CULL", None); os.environ.pop("RT_PAIR_BOXES", None)
+    img, st = gpu.render(forced, cam, prm)
+    assert np.array_equal(img, ref) and st["segments"] == sr["segments"], seed
+    img_d, sd = gpu.render(gpu.upload(desc), cam, prm)          # what the uploader picks by itself
+    assert np.array_equal(img_d, ref) and sd["segments"] == sr["segments"], seed
+    assert sum(st["prim_tests"][:5]) < sum(sr["prim_tests"][:5])
