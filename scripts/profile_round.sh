@@ -23,5 +23,7 @@ echo "configs done" >> gpurun_out/prof2/progress.log
 # sources it runs (scripts/collect_profiles.py repeats the conversion on the CPU side, where git is, for the committed file)
 SEG=$(grep -o "segments [0-9]*" gpurun_out/pmcR21.log | tail -1 | cut -d" " -f2)
 python3 scripts/pmc_to_json.py R2 $SEG profiles/r02_pmc_book1.json "scripts/pmc_passes.sh R2 (on the GPU box)" > /dev/null || exit 1
+SEG5=$(grep -o "segments [0-9]*" gpurun_out/pmcC5b1.log | tail -1 | cut -d" " -f2)
+python3 scripts/pmc_to_json.py C5b $SEG5 profiles/r02_pmc_c5.json "scripts/pmc_c5.sh C5b 16 (on the GPU box)" > /dev/null || exit 1
 timeout -k 10 500 python3 bench.py > gpurun_out/prof2/bench.json 2> gpurun_out/prof2/bench.err || exit 1
 cat gpurun_out/prof2/bench.json
