@@ -100,3 +100,12 @@ def test_rust_shim_covers_the_header():
         assert fields_rs == fields_c, (name, fields_rs, fields_c)
     patch = open(os.path.join(ROOT, "docs", "main_rs.patch")).read()
     assert "730,784c" in patch and "rt_render_multi_rgb8" in patch and "24a" in patch
+    # docs/scene_flatten.rs (the module the patch names): a record of every hittable / material / texture kind of the header is produced,
+    # and every kind constant it uses is declared by gpu_ffi.rs
+    fl = open(os.path.join(ROOT, "docs", "scene_flatten.rs")).read()
+    assert "mod scene_flatten;" in patch
+    for kind in re.findall(r"\b(RT_HIT_[A-Z_]+|RT_MAT_[A-Z_]+|RT_TEX_[A-Z_]+)\s*=", hdr):
+        assert re.search(r"\b%s\b" % kind, fl), kind + " is never produced by docs/scene_flatten.rs"
+        assert re.search(r"pub const %s: i32" % kind, rs), kind
+    for used in set(re.findall(r"\bRT_[A-Z_0-9]*[A-Z0-9]\b", fl)):     # not the "RT_HIT_*" of the comments
+        assert re.search(r"pub const %s\b" % used, rs), used + " is used by scene_flatten.rs but not declared in gpu_ffi.rs"
