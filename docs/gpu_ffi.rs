@@ -1,4 +1,4 @@
-//! gpu_ffi.rs — `extern "C"` bindings of include/rt_hip.h (ABI version 2) for the reference crate.
+//! gpu_ffi.rs — `extern "C"` bindings of include/rt_hip.h (ABI version 3) for the reference crate.
 //!
 //! Where it goes: `raytracer/src/gpu_ffi.rs`, with `mod gpu_ffi;` added to the module list of `main.rs:7-24`.
 //! It replaces nothing by itself: docs/main_rs.patch swaps the pixel loops `main.rs:730-784` for one call.
@@ -10,7 +10,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RT_ABI_VERSION: u32 = 2;
+pub const RT_ABI_VERSION: u32 = 3;
 
 // RtStatus
 pub const RT_OK: c_int = 0;
@@ -19,6 +19,7 @@ pub const RT_ERR_UNSUPPORTED: c_int = -2;
 pub const RT_ERR_DEVICE: c_int = -3;
 pub const RT_ERR_NO_DEVICE: c_int = -4;
 pub const RT_ERR_OOM: c_int = -5;
+pub const RT_ERR_PEER: c_int = -6;        // a collective render was called off because another rank failed; the message names it
 
 /// vec3.rs:5-8
 #[repr(C)] #[derive(Clone, Copy, Default, Debug)]
@@ -99,6 +100,24 @@ pub const RT_FLAG_FUSED: u32 = 8;         // diagnostic: the whole render by the
 pub struct RtParams {
     pub width: u32, pub height: u32, pub samples_per_pixel: u32, pub max_depth: u32, pub seed: u64,
     pub nan_policy: u32, pub flags: u32, pub tile_size: u32, pub shard_index: u32, pub shard_count: u32, pub pool_slots: u32,
+    pub tail_paths: u32, pub _pad: u32,
+}
+
+// RtUploadOptions.layout_flags: how a scene is laid out on the device (never what it looks like); 0 = the library's defaults
+pub const RT_LAYOUT_LISTS_AS_REFERENCE: u32 = 1;
+pub const RT_LAYOUT_LISTS_CULLED: u32 = 2;
+pub const RT_LAYOUT_NO_MEMBER_BOXES: u32 = 4;
+pub const RT_LAYOUT_MEMBER_BOXES: u32 = 8;
+pub const RT_LAYOUT_CHILD_ORDER_AS_REFERENCE: u32 = 16;
+pub const RT_LAYOUT_SCENE_IN_HBM: u32 = 32;
+pub const RT_LAYOUT_NODES_32B: u32 = 64;
+pub const RT_LAYOUT_NO_SHADE_TABLES_IN_LDS: u32 = 128;
+pub const RT_LAYOUT_NO_EXTEND_TABLES_IN_LDS: u32 = 256;
+pub const RT_LAYOUT_BINARY_NODES: u32 = 512;
+pub const RT_LAYOUT_REFERENCE_COUNTERS: u32 = 1 | 4 | 16 | 512;   // RtStats test counts = the reference's own
+#[repr(C)] #[derive(Clone, Copy, Default, Debug)]
+pub struct RtUploadOptions {
+    pub struct_bytes: u32, pub layout_flags: u32, pub lds_top_records: u32, pub octant_axes: u32, pub leaf_collapse: u32, pub list_park_cost: f32,
 }
 
 pub const RT_N_PRIM_TYPES: usize = 6;
@@ -135,6 +154,8 @@ extern "C" {
     pub fn rt_ctx_create(device_id: c_int, stream: *mut c_void, out_ctx: *mut *mut RtCtx) -> c_int;
     pub fn rt_ctx_destroy(ctx: *mut RtCtx) -> c_int;
     pub fn rt_scene_upload(ctx: *mut RtCtx, desc: *const RtSceneDesc, out_scene: *mut *mut RtScene) -> c_int;
+    /// the same with the device layout chosen per upload (NULL options = defaults); a threaded host cannot use process environment for that
+    pub fn rt_scene_upload_ex(ctx: *mut RtCtx, desc: *const RtSceneDesc, options: *const RtUploadOptions, out_scene: *mut *mut RtScene) -> c_int;
     pub fn rt_scene_destroy(ctx: *mut RtCtx, scene: *mut RtScene) -> c_int;
     pub fn rt_output_floats(params: *const RtParams, out_n: *mut u64) -> c_int;
     /// replaces the body of the pixel loops main.rs:731-784 (without write_color)
@@ -151,6 +172,8 @@ extern "C" {
     pub fn rt_ctx_create_multi(device_ids: *const c_int, n_devices: c_int, out_ctx: *mut *mut RtMultiCtx) -> c_int;
     pub fn rt_ctx_destroy_multi(ctx: *mut RtMultiCtx) -> c_int;
     pub fn rt_scene_upload_multi(ctx: *mut RtMultiCtx, desc: *const RtSceneDesc, out_scene: *mut *mut RtMultiScene) -> c_int;
+    pub fn rt_scene_upload_multi_ex(ctx: *mut RtMultiCtx, desc: *const RtSceneDesc, options: *const RtUploadOptions,
+                                    out_scene: *mut *mut RtMultiScene) -> c_int;
     pub fn rt_scene_destroy_multi(ctx: *mut RtMultiCtx, scene: *mut RtMultiScene) -> c_int;
     pub fn rt_render_multi(ctx: *mut RtMultiCtx, scene: *const RtMultiScene, cam: *const RtCamera, params: *const RtParams,
                            rgb_sum_host: *mut f32, stats: *mut RtStats) -> c_int;
@@ -169,8 +192,15 @@ extern "C" {
                             frame_device: *mut c_void) -> c_int;
     pub fn rt_untile_rgb8(params: *const RtParams, gathered: *const u8, rgb8: *mut u8) -> c_int;
 
+    // ---- the process's ROCm runtime libraries (refuses two HIP runtimes in one process); fault injection for failure-path tests ----
+    pub fn rt_runtime_libraries(out: *mut c_char, cap: u64) -> c_int;
+    pub fn rt_test_fail_next_renders(ctx: *mut RtCtx, n: u32) -> c_int;
+
     // ---- scene-compiler introspection (host only) ----
     pub fn rt_scene_compile_info(desc: *const RtSceneDesc, out: *mut RtCompileInfo) -> c_int;
+    pub fn rt_scene_compile_info_ex(desc: *const RtSceneDesc, options: *const RtUploadOptions, out: *mut RtCompileInfo) -> c_int;
+    pub fn rt_scene_compile_dump_ex(desc: *const RtSceneDesc, options: *const RtUploadOptions, nodes: *mut c_void, cap_nodes: u64,
+                                    spheres: *mut f32, sphere_meta: *mut u32, cap_spheres: u64) -> c_int;
     pub fn rt_scene_top_layout_check(desc: *const RtSceneDesc, max_top: u32, out_n_top: *mut u64) -> c_int;
     pub fn rt_scene_compile_dump(desc: *const RtSceneDesc, nodes: *mut c_void, cap_nodes: u64, spheres: *mut f32,
                                  sphere_meta: *mut u32, cap_spheres: u64) -> c_int;

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2u
+#define RT_ABI_VERSION 3u
 
 typedef enum RtStatus {
     RT_OK = 0,
@@ -37,7 +37,10 @@ typedef enum RtStatus {
     RT_ERR_UNSUPPORTED = -2,  /* graph shape the device compiler does not handle */
     RT_ERR_DEVICE = -3,       /* HIP runtime error (message has hipGetErrorString) */
     RT_ERR_NO_DEVICE = -4,    /* no usable GPU: the product path has no CPU fallback */
-    RT_ERR_OOM = -5
+    RT_ERR_OOM = -5,
+    RT_ERR_PEER = -6          /* a collective render (rt_render_gather / rt_render_multi) was called off because ANOTHER rank failed
+                                 its part; the message names the rank. Every rank of the collective returns — none waits for a
+                                 shard that will not come (the reference's convention is to panic: main.rs:762,777) */
 } RtStatus;
 
 /* vec3.rs:5-8 */
@@ -188,6 +191,9 @@ typedef struct RtParams {
     uint32_t shard_index;
     uint32_t shard_count;
     uint32_t pool_slots;          /* paths in flight; 0 = one per work item, up to 2^28 and to 70 % of the free device memory */
+    uint32_t tail_paths;          /* once at most this many paths are alive, ONE launch of the per-path kernel carries each of them to its end
+                                     instead of one launch pair per bounce (same frame bit for bit). 0 = default (2^18); 1 = never */
+    uint32_t _pad;
 } RtParams;
 
 #define RT_N_PRIM_TYPES 6  /* sphere, moving sphere, rect, triangle, medium, instance transform */
@@ -234,6 +240,35 @@ int rt_ctx_destroy(RtCtx* ctx);
    `desc`; nothing in it is retained after the call returns. */
 int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene);
 int rt_scene_destroy(RtCtx* ctx, RtScene* scene);
+
+/* ---- how a scene is laid out on the device: per upload, in the ABI (a host with threads cannot set process environment per scene) ----
+ * None of these changes a picture: they trade box tests, primitive tests and memory against each other. The defaults are what
+ * the library measures fastest; RT_LAYOUT_REFERENCE_COUNTERS is the layout whose RtStats test counts are the reference's own
+ * (HittableList::hit probing every member, hittable_list.rs:39-51; BVHNode::hit visiting left then right, bvh.rs:134-143) — the
+ * parity tests compare those counts with the CPU oracle's. Environment variables of the same names as in scripts/ still exist
+ * as overrides for experiments; no test and no host depends on them. */
+enum {
+    RT_LAYOUT_LISTS_AS_REFERENCE = 1u,   /* every HittableList member in front of every ray, nothing tested at the start of a walk */
+    RT_LAYOUT_LISTS_CULLED = 2u,         /* members behind culling boxes even in a scene that is only a list (default: when the scene holds a BVH of >= 32 members) */
+    RT_LAYOUT_NO_MEMBER_BOXES = 4u,      /* the two members of a span-2 BVH node tested directly, as bvh.rs:99-107 does (default: a sphere gets a box of its own in LDS-sized scenes) */
+    RT_LAYOUT_MEMBER_BOXES = 8u,         /* ... boxes of their own in any scene */
+    RT_LAYOUT_CHILD_ORDER_AS_REFERENCE = 16u, /* one record array, left child before right (default for scenes in HBM: one array per direction octant, near child first) */
+    RT_LAYOUT_SCENE_IN_HBM = 32u,        /* do not stage a small scene in LDS */
+    RT_LAYOUT_NODES_32B = 64u,           /* scenes in HBM: 32-byte f32 records (with the top of the tree in LDS) instead of compressed ones */
+    RT_LAYOUT_NO_SHADE_TABLES_IN_LDS = 128u,
+    RT_LAYOUT_NO_EXTEND_TABLES_IN_LDS = 256u,
+    RT_LAYOUT_BINARY_NODES = 512u,       /* scenes in HBM: two-child compressed records instead of the 8-wide ones */
+    RT_LAYOUT_REFERENCE_COUNTERS = 1u | 4u | 16u | 512u
+};
+typedef struct RtUploadOptions {
+    uint32_t struct_bytes;     /* sizeof(RtUploadOptions) as the caller compiled it (the struct may grow at its end) */
+    uint32_t layout_flags;     /* RT_LAYOUT_* */
+    uint32_t lds_top_records;  /* RT_LAYOUT_NODES_32B: records of the top of the tree kept in LDS; 0 = default (1024) */
+    uint32_t octant_axes;      /* near-first record arrays: 0 = the library picks the axes that matter; else 8 | mask (x = 1, y = 2, z = 4) */
+    uint32_t leaf_collapse;    /* a box node whose subtree is <= n primitives of one kind becomes a leaf; 0/1 = off (default) */
+    float    list_park_cost;   /* cost of a stop at a leaf in primitive tests, for the grouping of culled list members; 0 = default (6) */
+} RtUploadOptions;
+int rt_scene_upload_ex(RtCtx* ctx, const RtSceneDesc* desc, const RtUploadOptions* options /* NULL = defaults */, RtScene** out_scene);
 
 /* Number of floats rt_render writes: 3 * pixels covered by this shard's tiles. For
    shard_count <= 1 this is 3*width*height. */
@@ -282,7 +317,8 @@ typedef struct RtMultiCtx RtMultiCtx;
 typedef struct RtMultiScene RtMultiScene;
 int rt_ctx_create_multi(const int* device_ids, int n_devices, RtMultiCtx** out_ctx);
 int rt_ctx_destroy_multi(RtMultiCtx* ctx);
-int rt_scene_upload_multi(RtMultiCtx* ctx, const RtSceneDesc* desc, RtMultiScene** out_scene);   /* replicated on every device */
+int rt_scene_upload_multi(RtMultiCtx* ctx, const RtSceneDesc* desc, RtMultiScene** out_scene);   /* compiled once, replicated on every device */
+int rt_scene_upload_multi_ex(RtMultiCtx* ctx, const RtSceneDesc* desc, const RtUploadOptions* options, RtMultiScene** out_scene);
 int rt_scene_destroy_multi(RtMultiCtx* ctx, RtMultiScene* scene);
 /* Full frame to HOST memory: rgb_sum_host[(y*width + x)*3 + c] f32 sums, or rgb8_host[...] after write_color.
    params->shard_index / shard_count are ignored (the library shards over its devices); tile_size 0 = 32. */
@@ -321,16 +357,31 @@ typedef struct RtCompileInfo {
     uint32_t fits_lds;      /* nodes + sphere records fit the LDS staging budget */
 } RtCompileInfo;
 int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out);
+int rt_scene_compile_info_ex(const RtSceneDesc* desc, const RtUploadOptions* options, RtCompileInfo* out);
 /* Copies the compiled node records (32 B each: f32 min[3], u32 skip, f32 max[3], u32 leaf) and the
    sphere records (f32 center[3], radius) + per-sphere meta words. Any output pointer may be NULL. */
 int rt_scene_compile_dump(const RtSceneDesc* desc, void* nodes, uint64_t cap_nodes,
                           float* spheres, uint32_t* sphere_meta, uint64_t cap_spheres);
+int rt_scene_compile_dump_ex(const RtSceneDesc* desc, const RtUploadOptions* options, void* nodes, uint64_t cap_nodes,
+                             float* spheres, uint32_t* sphere_meta, uint64_t cap_spheres);
 
 /* Builds the layout used when a scene does not fit LDS as a whole — the array in HBM plus an LDS copy of the top of the tree (at most
    max_top records), linked in one address space — and checks it on the host: the walk that passes every box enumerates all records
    in pre-order, every skip link lands where the plain array's does, both copies of a top record agree. *out_n_top = records in
    the top (0: no top was built, e.g. the whole scene fits). */
 int rt_scene_top_layout_check(const RtSceneDesc* desc, uint32_t max_top, uint64_t* out_n_top);
+
+/* ---- the process's ROCm runtime libraries ----
+ * Writes the paths of the mapped libamdhip64 / libhsa-runtime64 / librccl objects, one per line, into `out` (NUL-terminated, cut at
+ * `cap`). Returns RT_ERR_DEVICE when any of them is mapped TWICE (two copies under different paths): a process then holds two HIP
+ * runtimes with separate device state and dies at exit in their static destructors ("double free or corruption") — what happens when
+ * PyTorch (which bundles its own copies under other file names) is imported AFTER this library has bound the system's. Load PyTorch
+ * first: its copies carry the system's sonames and are then shared. rt_ctx_create makes this check itself and refuses. */
+int rt_runtime_libraries(char* out, uint64_t cap);
+
+/* Fault injection for the failure-path tests: the next `n` renders on this context fail with RT_ERR_DEVICE before any kernel is
+   launched (n = 0 disarms). Lets a one-GPU box rehearse "one rank of a collective render fails". */
+int rt_test_fail_next_renders(RtCtx* ctx, uint32_t n);
 
 const char* rt_last_error(const RtCtx* ctx);  /* ctx may be NULL: last error of this thread */
 uint32_t rt_abi_version(void);

@@ -1,10 +1,10 @@
 """ctypes mirror of include/rt_hip.h and include/rt_host.h (struct layouts must match the headers)."""
 import ctypes as C
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 RT_N_PRIM_TYPES = 6
 
-RT_OK, RT_ERR_INVALID, RT_ERR_UNSUPPORTED, RT_ERR_DEVICE, RT_ERR_NO_DEVICE, RT_ERR_OOM = 0, -1, -2, -3, -4, -5
+RT_OK, RT_ERR_INVALID, RT_ERR_UNSUPPORTED, RT_ERR_DEVICE, RT_ERR_NO_DEVICE, RT_ERR_OOM, RT_ERR_PEER = 0, -1, -2, -3, -4, -5, -6
 
 RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_NOISE, RT_TEX_IMAGE = 0, 1, 2, 3
 RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT, RT_MAT_ISOTROPIC = 0, 1, 2, 3, 4
@@ -16,6 +16,10 @@ RT_NAN_PER_SAMPLE, RT_NAN_REFERENCE = 0, 1
 RT_FLAG_COUNTERS, RT_FLAG_TIMING, RT_FLAG_SAMPLE_BLOCKS, RT_FLAG_FUSED = 1, 2, 4, 8
 RT_OUT_RGB_SUM_F32, RT_OUT_RGB8 = 0, 1
 RT_COMM_ID_BYTES = 128
+# RtUploadOptions.layout_flags
+(RT_LAYOUT_LISTS_AS_REFERENCE, RT_LAYOUT_LISTS_CULLED, RT_LAYOUT_NO_MEMBER_BOXES, RT_LAYOUT_MEMBER_BOXES, RT_LAYOUT_CHILD_ORDER_AS_REFERENCE,
+ RT_LAYOUT_SCENE_IN_HBM, RT_LAYOUT_NODES_32B, RT_LAYOUT_NO_SHADE_TABLES_IN_LDS, RT_LAYOUT_NO_EXTEND_TABLES_IN_LDS, RT_LAYOUT_BINARY_NODES) = (1 << k for k in range(10))
+RT_LAYOUT_REFERENCE_COUNTERS = RT_LAYOUT_LISTS_AS_REFERENCE | RT_LAYOUT_NO_MEMBER_BOXES | RT_LAYOUT_CHILD_ORDER_AS_REFERENCE | RT_LAYOUT_BINARY_NODES
 
 
 class RtVec3(C.Structure):
@@ -65,7 +69,8 @@ class RtSceneDesc(C.Structure):
 class RtParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples_per_pixel", C.c_uint32), ("max_depth", C.c_uint32),
                 ("seed", C.c_uint64), ("nan_policy", C.c_uint32), ("flags", C.c_uint32),
-                ("tile_size", C.c_uint32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("pool_slots", C.c_uint32)]
+                ("tile_size", C.c_uint32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("pool_slots", C.c_uint32),
+                ("tail_paths", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class RtStats(C.Structure):
@@ -92,12 +97,18 @@ class RtCompileInfo(C.Structure):
                 ("features", C.c_uint32), ("fits_lds", C.c_uint32)]
 
 
+class RtUploadOptions(C.Structure):
+    _fields_ = [("struct_bytes", C.c_uint32), ("layout_flags", C.c_uint32), ("lds_top_records", C.c_uint32), ("octant_axes", C.c_uint32),
+                ("leaf_collapse", C.c_uint32), ("list_park_cost", C.c_float)]
+
+
 # every symbol include/rt_hip.h and include/rt_host.h declare
 RT_HIP_SYMBOLS = ["rt_ctx_create", "rt_ctx_destroy", "rt_scene_upload", "rt_scene_destroy", "rt_output_floats", "rt_render",
                   "rt_render_device", "rt_untile", "rt_resolve_device", "rt_last_error", "rt_abi_version", "rt_scene_compile_info",
                   "rt_scene_compile_dump", "rt_ctx_create_multi", "rt_ctx_destroy_multi", "rt_scene_upload_multi", "rt_scene_destroy_multi",
                   "rt_render_multi", "rt_render_multi_rgb8", "rt_last_error_multi", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_selftest",
-                  "rt_render_gather", "rt_untile_rgb8", "rt_untile_device", "rt_scene_top_layout_check"]
+                  "rt_render_gather", "rt_untile_rgb8", "rt_untile_device", "rt_scene_top_layout_check", "rt_scene_upload_ex", "rt_scene_upload_multi_ex",
+                  "rt_runtime_libraries", "rt_test_fail_next_renders", "rt_scene_compile_info_ex", "rt_scene_compile_dump_ex"]
 RT_HOST_SYMBOLS = ["rt_host_scene_create", "rt_host_scene_desc", "rt_host_scene_camera", "rt_host_scene_destroy", "rt_host_camera_new",
                    "rt_host_write_color", "rt_host_tonemap", "rt_host_write_png"]
 
@@ -116,6 +127,14 @@ def declare(lib):
     lib.rt_ctx_destroy.argtypes = [vp]
     lib.rt_scene_upload.restype = i32
     lib.rt_scene_upload.argtypes = [vp, P(RtSceneDesc), P(vp)]
+    lib.rt_scene_upload_ex.restype = i32
+    lib.rt_scene_upload_ex.argtypes = [vp, P(RtSceneDesc), P(RtUploadOptions), P(vp)]
+    lib.rt_scene_upload_multi_ex.restype = i32
+    lib.rt_scene_upload_multi_ex.argtypes = [vp, P(RtSceneDesc), P(RtUploadOptions), P(vp)]
+    lib.rt_runtime_libraries.restype = i32
+    lib.rt_runtime_libraries.argtypes = [C.c_char_p, u64]
+    lib.rt_test_fail_next_renders.restype = i32
+    lib.rt_test_fail_next_renders.argtypes = [vp, u32]
     lib.rt_scene_destroy.restype = i32
     lib.rt_scene_destroy.argtypes = [vp, vp]
     lib.rt_output_floats.restype = i32
@@ -130,6 +149,10 @@ def declare(lib):
     lib.rt_resolve_device.argtypes = [vp, vp, u32, u32, u32, vp]
     lib.rt_scene_compile_info.restype = i32
     lib.rt_scene_compile_info.argtypes = [P(RtSceneDesc), P(RtCompileInfo)]
+    lib.rt_scene_compile_info_ex.restype = i32
+    lib.rt_scene_compile_info_ex.argtypes = [P(RtSceneDesc), P(RtUploadOptions), P(RtCompileInfo)]
+    lib.rt_scene_compile_dump_ex.restype = i32
+    lib.rt_scene_compile_dump_ex.argtypes = [P(RtSceneDesc), P(RtUploadOptions), vp, u64, P(C.c_float), P(u32), u64]
     lib.rt_scene_compile_dump.restype = i32
     lib.rt_scene_compile_dump.argtypes = [P(RtSceneDesc), vp, u64, P(C.c_float), P(u32), u64]
     lib.rt_untile_rgb8.restype = i32

@@ -42,8 +42,8 @@ def _check(code, ctx=None):
 
 
 def make_params(width, height, spp, max_depth=50, seed=1, nan_policy=A.RT_NAN_PER_SAMPLE, flags=0, tile_size=0, shard_index=0,
-                shard_count=1, pool_slots=0):
-    return A.RtParams(width, height, spp, max_depth, seed, nan_policy, flags, tile_size, shard_index, shard_count, pool_slots)
+                shard_count=1, pool_slots=0, tail_paths=0):
+    return A.RtParams(width, height, spp, max_depth, seed, nan_policy, flags, tile_size, shard_index, shard_count, pool_slots, tail_paths, 0)
 
 
 def output_floats(params):
@@ -105,23 +105,25 @@ def comm_unique_id():
     return bytes(buf)
 
 
-def compile_info(desc):
-    """rt_scene_compile_info: what the scene compiler makes of a graph (host only)."""
+def compile_info(desc, layout_flags=0):
+    """rt_scene_compile_info[_ex]: what the scene compiler makes of a graph (host only)."""
     info = A.RtCompileInfo()
-    _check(lib().rt_scene_compile_info(C.byref(desc), C.byref(info)))
+    opt = upload_options(layout_flags)
+    _check(lib().rt_scene_compile_info_ex(C.byref(desc), C.byref(opt), C.byref(info)))
     return {n: getattr(info, n) for n, _ in info._fields_}
 
 
-def compile_dump(desc):
-    """rt_scene_compile_dump: (nodes structured array, spheres (n,4) f32, sphere_meta u32)."""
-    info = compile_info(desc)
+def compile_dump(desc, layout_flags=0):
+    """rt_scene_compile_dump[_ex]: (nodes structured array, spheres (n,4) f32, sphere_meta u32)."""
+    info = compile_info(desc, layout_flags)
+    opt = upload_options(layout_flags)
     node_t = np.dtype([("mn", np.float32, 3), ("skip", np.uint32), ("mx", np.float32, 3), ("leaf", np.uint32)])
     nodes = np.zeros(info["n_nodes"], dtype=node_t)
     n_s = max(1, info["n_spheres"] + info["n_media"])   # media boundaries add private spheres
     spheres = np.zeros((n_s, 4), dtype=np.float32)
     meta = np.zeros(n_s, dtype=np.uint32)
-    _check(lib().rt_scene_compile_dump(C.byref(desc), nodes.ctypes.data_as(C.c_void_p), len(nodes), spheres.ctypes.data_as(C.POINTER(C.c_float)),
-                                       meta.ctypes.data_as(C.POINTER(C.c_uint32)), n_s))
+    _check(lib().rt_scene_compile_dump_ex(C.byref(desc), C.byref(opt), nodes.ctypes.data_as(C.c_void_p), len(nodes), spheres.ctypes.data_as(C.POINTER(C.c_float)),
+                                          meta.ctypes.data_as(C.POINTER(C.c_uint32)), n_s))
     return nodes, spheres[:info["n_spheres"]], meta[:info["n_spheres"]]
 
 
@@ -160,11 +162,23 @@ class HostScene:
             pass
 
 
+def upload_options(layout_flags=0, lds_top_records=0, octant_axes=0, leaf_collapse=0, list_park_cost=0.0):
+    """RtUploadOptions (include/rt_hip.h): how the scene is laid out on the device; never what it looks like."""
+    return A.RtUploadOptions(C.sizeof(A.RtUploadOptions), layout_flags, lds_top_records, octant_axes, leaf_collapse, list_park_cost)
+
+
+def runtime_libraries():
+    """rt_runtime_libraries: (paths of the mapped libamdhip64 / libhsa-runtime64 / librccl objects, ok) — ok is False when one is mapped twice."""
+    buf = C.create_string_buffer(8192)
+    code = lib().rt_runtime_libraries(buf, len(buf))
+    return [p for p in buf.value.decode().split("\n") if p], code == A.RT_OK
+
+
 class Scene:
-    def __init__(self, ctx, desc):
+    def __init__(self, ctx, desc, options=None):
         self.ctx = ctx
         self._h = C.c_void_p()
-        _check(lib().rt_scene_upload(ctx._h, C.byref(desc), C.byref(self._h)), ctx._h)
+        _check(lib().rt_scene_upload_ex(ctx._h, C.byref(desc), C.byref(options) if options is not None else None, C.byref(self._h)), ctx._h)
 
     def close(self):
         if self._h and self.ctx._h:
@@ -185,8 +199,13 @@ class Context:
         self._h = C.c_void_p()
         _check(lib().rt_ctx_create(device_id, C.c_void_p(stream) if stream else None, C.byref(self._h)))
 
-    def upload(self, desc):
-        return Scene(self, desc)
+    def upload(self, desc, layout_flags=0, **more):
+        """rt_scene_upload_ex; layout_flags = RT_LAYOUT_* (A.RT_LAYOUT_REFERENCE_COUNTERS: the layout whose test counts are the reference's)."""
+        return Scene(self, desc, upload_options(layout_flags, **more) if (layout_flags or more) else None)
+
+    def fail_next_renders(self, n):
+        """rt_test_fail_next_renders: fault injection for the failure-path tests."""
+        _check(lib().rt_test_fail_next_renders(self._h, n), self._h)
 
     def render(self, scene, cam, params):
         """rt_render: returns (rgb_sum float32 array, stats dict). Full frame -> (H, W, 3); sharded -> flat."""
@@ -238,10 +257,10 @@ class Context:
 
 
 class MultiScene:
-    def __init__(self, mctx, desc):
+    def __init__(self, mctx, desc, options=None):
         self.mctx = mctx
         self._h = C.c_void_p()
-        code = lib().rt_scene_upload_multi(mctx._h, C.byref(desc), C.byref(self._h))
+        code = lib().rt_scene_upload_multi_ex(mctx._h, C.byref(desc), C.byref(options) if options is not None else None, C.byref(self._h))
         if code != A.RT_OK:
             raise RtError(code, lib().rt_last_error_multi(mctx._h).decode())
 
@@ -267,8 +286,8 @@ class MultiContext:
         _check(lib().rt_ctx_create_multi(ids, len(device_ids), C.byref(self._h)))
         self.n = len(device_ids)
 
-    def upload(self, desc):
-        return MultiScene(self, desc)
+    def upload(self, desc, layout_flags=0, **more):
+        return MultiScene(self, desc, upload_options(layout_flags, **more) if (layout_flags or more) else None)
 
     def _render(self, fn, scene, cam, params, out, ptr_t):
         st = A.RtStats()

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <limits>
+#include <memory>
 #include <vector>
 
 #include "rt_internal.hpp"
@@ -39,6 +40,7 @@ int rti::validate_params(RtCtx* ctx, const RtParams* p) {
     if (!p) return set_err(ctx, RT_ERR_INVALID, "params is null");
     if (p->width < 2 || p->height < 2) return set_err(ctx, RT_ERR_INVALID, "width and height must be >= 2 (u = (i+rnd)/(W-1), main.rs:752)");
     if (p->width > 65536 || p->height > 65536) return set_err(ctx, RT_ERR_INVALID, "image too large");
+    if ((uint64_t)p->width * p->height * 3ull > 0xFFFFFFFFull) return set_err(ctx, RT_ERR_INVALID, "image too large (width * height * 3 must fit 32 bits; shard the render)");
     if (p->samples_per_pixel == 0) return set_err(ctx, RT_ERR_INVALID, "samples_per_pixel must be >= 1");
     if (p->max_depth == 0 || p->max_depth > 255) return set_err(ctx, RT_ERR_INVALID, "max_depth must be in 1..255");
     if (p->nan_policy > 1) return set_err(ctx, RT_ERR_INVALID, "bad nan_policy");
@@ -52,6 +54,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
 // A render that fails half way (a HIP error, out of memory) must not leave work or recorded events in flight on the
 // caller's stream: drain it before the error goes back.
 int rti::render_checked(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, void* d_out, RtStats* stats) {
+    if (ctx->fail_renders != 0u) { --ctx->fail_renders; return set_err(ctx, RT_ERR_DEVICE, "injected failure (rt_test_fail_next_renders)"); }
     const int r = render_impl(ctx, scene, cam, prm, d_out, stats);
     if (r != RT_OK) { const std::string keep = ctx->err; (void)hipStreamSynchronize(ctx->stream); (void)hipGetLastError(); ctx->err = keep; g_last_error = keep; }
     return r;
@@ -89,6 +92,7 @@ static int ctx_init(RtCtx* ctx, void* stream) {
     else { HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
     HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_count, 8 * rtk::kQueues * sizeof(uint32_t), hipHostMallocDefault));   // ring of 8 x (one pool size per queue)
     HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_counters, sizeof(unsigned long long) * 16, hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_words, 128 * sizeof(uint32_t), hipHostMallocDefault));
     return RT_OK;
 }
 
@@ -104,6 +108,10 @@ int rt_ctx_create(int device_id, void* stream, RtCtx** out_ctx) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return set_err(nullptr, RT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     if (device_id < 0 || device_id >= n) return set_err(nullptr, RT_ERR_INVALID, "device_id out of range");
+    {   // two HIP runtimes in one process end in heap corruption at exit ("the abort of round 2"): refuse early, with the reason
+        std::string listing, why;
+        if (!runtime_libraries_ok(listing, why)) return set_err(nullptr, RT_ERR_DEVICE, why);
+    }
     RtCtx* ctx = new RtCtx();
     ctx->device = device_id;
     const int rc = ctx_init(ctx, stream);
@@ -120,8 +128,11 @@ int rt_ctx_destroy(RtCtx* ctx) {
     comm_release(ctx);
     ctx->blocksum.release(); ctx->counters.release(); ctx->out_tmp.release(); ctx->tile_prefix.release(); ctx->shard_tmp.release();
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->ev_gather) if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_count) (void)hipHostFree(ctx->h_count);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->h_words) (void)hipHostFree(ctx->h_words);
+    ctx->comm_words.release();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -323,63 +334,98 @@ static size_t lds_scene_bytes(const rtc::CompiledScene& cs) {
     return (cs.nodes.size() + 2 + twins) * 32 + cs.spheres.size() * 16;
 }
 
-int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
-    if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
-    if (!desc || !out_scene) return set_err(ctx, RT_ERR_INVALID, "desc / out_scene is null");
-    *out_scene = nullptr;
+}  // extern "C"
+
+// ---- layout options: RtUploadOptions of the ABI, resolved once per upload ---------------------------------------------------------------
+// Environment variables are OVERRIDES for the experiment scripts under scripts/ only (they predate the ABI fields and keep the A/B
+// scripts one-liners); no test and no host path sets them. A process that never sets them gets exactly what its RtUploadOptions say.
+struct rti::UploadOpts {
+    rtc::CompileOptions compile;
+    bool lds_scene = true, node16 = true, octant_order = true, shade_lds = true, perlin_lds = true, extend_lds_tables = true, wide_nodes = true;
+    uint32_t max_top = 1024u, octant_axes = 0u /* 0 = pick; else 8 | mask */;
+};
+static rti::UploadOpts resolve_options(const RtUploadOptions* o) {
+    rti::UploadOpts u;
+    if (o && o->struct_bytes >= 8u) {
+        const uint32_t f = o->layout_flags;
+        if (f & RT_LAYOUT_LISTS_AS_REFERENCE) u.compile.cull_lists = 0; else if (f & RT_LAYOUT_LISTS_CULLED) u.compile.cull_lists = 1;
+        if (f & RT_LAYOUT_NO_MEMBER_BOXES) u.compile.member_boxes = 0; else if (f & RT_LAYOUT_MEMBER_BOXES) u.compile.member_boxes = 1;
+        u.octant_order = !(f & RT_LAYOUT_CHILD_ORDER_AS_REFERENCE);
+        u.lds_scene = !(f & RT_LAYOUT_SCENE_IN_HBM);
+        u.node16 = !(f & RT_LAYOUT_NODES_32B);
+        u.shade_lds = u.perlin_lds = !(f & RT_LAYOUT_NO_SHADE_TABLES_IN_LDS);
+        u.extend_lds_tables = !(f & RT_LAYOUT_NO_EXTEND_TABLES_IN_LDS);
+        u.wide_nodes = !(f & RT_LAYOUT_BINARY_NODES);
+        if (o->struct_bytes >= 12u && o->lds_top_records) u.max_top = o->lds_top_records;
+        if (o->struct_bytes >= 16u && o->octant_axes) u.octant_axes = 8u | (o->octant_axes & 7u);
+        if (o->struct_bytes >= 20u) u.compile.leaf_collapse = o->leaf_collapse;
+        if (o->struct_bytes >= 24u && o->list_park_cost > 0.f) u.compile.park_cost = o->list_park_cost;
+    }
+    auto env = [](const char* n) -> const char* { const char* e = getenv(n); return e && e[0] ? e : nullptr; };
+    if (const char* e = env("RT_LIST_CULL")) u.compile.cull_lists = e[0] == '2' ? 1 : (e[0] == '0' ? 0 : u.compile.cull_lists);
+    if (const char* e = env("RT_PAIR_BOXES")) u.compile.member_boxes = e[0] == '2' ? 1 : (e[0] == '0' ? 0 : u.compile.member_boxes);
+    if (const char* e = env("RT_LIST_PARK_COST")) u.compile.park_cost = std::max(0.0, std::atof(e));
+    if (const char* e = env("RT_LEAF_COLLAPSE")) u.compile.leaf_collapse = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = env("RT_LDS_SCENE")) u.lds_scene = u.lds_scene && e[0] != '0';
+    if (const char* e = env("RT_TOP_NODES")) u.max_top = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = env("RT_NODE16")) u.node16 = u.node16 && e[0] != '0';
+    if (const char* e = env("RT_OCTANT_ORDER")) u.octant_order = u.octant_order && e[0] != '0';
+    if (const char* e = env("RT_OCTANT_AXES")) u.octant_axes = 8u | ((uint32_t)std::strtoul(e, nullptr, 10) & 7u);
+    if (const char* e = env("RT_SHADE_LDS")) u.shade_lds = u.shade_lds && e[0] != '0';
+    if (const char* e = env("RT_SHADE_PERLIN_LDS")) u.perlin_lds = e[0] != '0';
+    if (const char* e = env("RT_EXTEND_LDS_TABLES")) u.extend_lds_tables = u.extend_lds_tables && e[0] != '0';
+    if (const char* e = env("RT_WIDE_NODES")) u.wide_nodes = u.wide_nodes && e[0] != '0';
+    u.max_top = std::min<uint32_t>(u.max_top, (128u * 1024u) / 32u);
+    return u;
+}
+
+// ---- the host image of a scene: everything an upload copies to a device, built ONCE (rt_scene_upload_multi uploads it n times) ---------
+struct rti::SceneImage {
     rtc::CompiledScene cs;
-    const int rc = rtc::compile_scene(*desc, cs);
-    if (rc != RT_OK) return set_err(ctx, rc, "scene: " + cs.error);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    RtScene* s = new RtScene();
-    int r = RT_OK;
-    auto up = [&](auto& buf, const auto& vec) { if (r == RT_OK) r = upload(ctx, buf, vec); };
-    bool in_lds = lds_scene_bytes(cs) <= kLdsSceneBudget;
-    if (const char* e = getenv("RT_LDS_SCENE")) in_lds = in_lds && e[0] != '0';     // 0: walk a small scene from HBM too (experiments)
-    // RT_TOP_NODES: records of the top of the tree kept in LDS for scenes that do not fit as a whole (0 = none)
-    uint32_t max_top = 1024u;
-    if (const char* e = getenv("RT_TOP_NODES")) max_top = (uint32_t)std::strtoul(e, nullptr, 10);
-    max_top = std::min<uint32_t>(max_top, (128u * 1024u) / 32u);
-    DevNodes dn;   // alive until the stream sync below
+    DevNodes dn;
     std::vector<rtd::Node16> n16;
     float grid_lo[3] = {0, 0, 0}, grid_scale[3] = {1, 1, 1};
-    // RT_NODE16=0: keep 32-byte records (with the top of the tree in LDS) for a scene that does not fit LDS; default: 16-byte records
-    bool want16 = !in_lds;
-    if (const char* e = getenv("RT_NODE16")) want16 = want16 && e[0] != '0';
-    bool c16 = want16 && device_nodes16(cs.nodes, n16, grid_lo, grid_scale);
-    // the record array once per direction octant (octant_order above), as long as 31-bit links reach; RT_OCTANT_ORDER=0: one array, the
-    // reference's order (left, then right) — the order whose visit counts the tests compare with the CPU restatement's
+    bool in_lds = false, c16 = false, top = false;
     uint32_t oct_stride = 0u, oct_mask = 7u;
+    std::vector<unsigned char> blob, eblob;
+    uint32_t sb[12] = {0}, perlin_only = 0u, eb[4] = {0}, eb_rect_stride = 32u;
+    uint32_t features = 0u;
+};
+void rti::scene_image_free(SceneImage* im) { delete im; }
+
+int rti::scene_image_build(const RtSceneDesc* desc, const RtUploadOptions* options, SceneImage** out, std::string& err) {
+    *out = nullptr;
+    const UploadOpts opt = resolve_options(options);
+    std::unique_ptr<SceneImage> im(new SceneImage());
+    rtc::CompiledScene& cs = im->cs;
+    const int rc = rtc::compile_scene(*desc, opt.compile, cs);
+    if (rc != RT_OK) { err = "scene: " + cs.error; return rc; }
+    im->in_lds = opt.lds_scene && lds_scene_bytes(cs) <= kLdsSceneBudget;
+    // 16-byte compressed records for a scene that does not fit LDS (RT_LAYOUT_NODES_32B: 32-byte records with the top of the tree in LDS)
+    im->c16 = !im->in_lds && opt.node16 && device_nodes16(cs.nodes, im->n16, im->grid_lo, im->grid_scale);
+    // the record array once per direction octant (octant_order above), as long as 31-bit links reach; RT_LAYOUT_CHILD_ORDER_AS_REFERENCE: one
+    // array, the reference's order (left, then right) — the order whose visit counts the tests compare with the CPU restatement's
     {
-        bool octants = c16 && 8ull * (cs.nodes.size() + 2) * 16ull < 0x7FFFFFF0ull;
-        if (const char* e = getenv("RT_OCTANT_ORDER")) octants = octants && e[0] != '0';
+        bool octants = im->c16 && opt.octant_order && 8ull * (cs.nodes.size() + 2) * 16ull < 0x7FFFFFF0ull;
         if (octants) {
             const uint32_t stride = (uint32_t)((cs.nodes.size() + 2) * 16);
             std::vector<rtd::Node16> all; all.reserve(8 * (cs.nodes.size() + 2));
             std::vector<rtd::Node> ordered; std::vector<rtd::Node16> one;
-            oct_mask = deciding_axes(cs.nodes);
-            if (const char* e = getenv("RT_OCTANT_AXES")) oct_mask = (uint32_t)std::strtoul(e, nullptr, 10) & 7u;
+            uint32_t mask = (opt.octant_axes & 8u) ? (opt.octant_axes & 7u) : deciding_axes(cs.nodes);
             for (uint32_t oct = 0; oct < 8 && octants; ++oct) {
-                if ((oct & ~oct_mask) != 0u) { all.resize(all.size() + cs.nodes.size() + 2); continue; }      // never selected (kernels.hip go_root): left empty, never touched
+                if ((oct & ~mask) != 0u) { all.resize(all.size() + cs.nodes.size() + 2); continue; }      // never selected (kernels.hip go_root): left empty, never touched
                 octant_order(cs.nodes, oct, ordered);
-                octants = ordered.size() == cs.nodes.size() && device_nodes16(ordered, one, grid_lo, grid_scale, oct * stride, true);
+                octants = ordered.size() == cs.nodes.size() && device_nodes16(ordered, one, im->grid_lo, im->grid_scale, oct * stride, true);
                 all.insert(all.end(), one.begin(), one.end());
             }
-            if (octants) { n16.swap(all); oct_stride = stride; }
+            if (octants) { im->n16.swap(all); im->oct_stride = stride; im->oct_mask = mask; }
         }
     }
-    if (!c16 && !device_nodes(cs.nodes, in_lds ? 0u : max_top, dn)) { delete s; return set_err(ctx, RT_ERR_UNSUPPORTED, "scene: node array beyond 4 GB"); }
-    const bool top = !c16 && dn.n_top != 0u;
-    if (top) up(s->top_nodes, dn.top);
-    if (c16) up(s->nodes, n16); else up(s->nodes, dn.main);
-    up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
-    up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->media, cs.media);
-    up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
-    up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
-    // k_shade's small tables as one blob for LDS staging (kernels.h SceneDev::shade_blob): only when it is small. RT_SHADE_LDS=0 turns it off.
-    std::vector<unsigned char> blob;
-    uint32_t sb[12] = {0}, perlin_only = 0u;
+    if (!im->c16 && !device_nodes(cs.nodes, im->in_lds ? 0u : opt.max_top, im->dn)) { err = "scene: node array beyond 4 GB"; return RT_ERR_UNSUPPORTED; }
+    im->top = !im->c16 && im->dn.n_top != 0u;
+    // k_shade's small tables as one blob for LDS staging (kernels.h SceneDev::shade_blob): only when it is small
     {
+        std::vector<unsigned char>& blob = im->blob; uint32_t* sb = im->sb;
         auto put = [&](const void* p, size_t bytes) { const uint32_t at = (uint32_t)blob.size(); blob.resize((blob.size() + bytes + 15) & ~(size_t)15, 0); if (bytes) std::memcpy(blob.data() + at, p, bytes); return at; };
         sb[0] = put(cs.spheres.data(), cs.spheres.size() * 16); sb[1] = put(cs.sphere_meta.data(), cs.sphere_meta.size() * 4);
         sb[2] = put(cs.rects.data(), cs.rects.size() * 16); sb[3] = put(cs.rect_meta.data(), cs.rect_meta.size() * 4);
@@ -388,35 +434,27 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
         sb[8] = put(cs.xforms.data(), cs.xforms.size() * sizeof(rtd::Xform)); sb[9] = put(cs.wraps.data(), cs.wraps.size() * sizeof(rtd::Wrap));
         sb[10] = put(cs.lights.data(), cs.lights.size() * sizeof(rtd::Light)); sb[11] = put(cs.textures.data(), cs.textures.size() * sizeof(rtd::Texture));
         // every 512-path workgroup pays for the copy: measured on Cornell (1.6 KB) k_shade 87.4 -> 75.2 ms, on book-1 (19 KB) 36.8 -> 40.2 ms
-        bool on = blob.size() <= 8 * 1024;
-        if (const char* e = getenv("RT_SHADE_LDS")) on = on && e[0] != '0';
-        if (!on) blob.clear();
+        if (!(opt.shade_lds && blob.size() <= 8 * 1024)) blob.clear();
         // a scene with noise textures whose other tables are too big to stage: the Perlin tables alone (7 KB each). A turbulence is a chain of
-        // 7 x 8 x 4 dependent look-ups, and a wave waits for the one lane that makes it (RT_SHADE_PERLIN_LDS=0 turns this off)
-        if (blob.empty() && !cs.perlins.empty() && cs.perlins.size() * sizeof(rtd::PerlinTable) <= 16 * 1024) {
-            bool pon = true;
-            if (const char* e = getenv("RT_SHADE_PERLIN_LDS")) pon = e[0] != '0';
-            if (pon) {
-                put(cs.perlins.data(), cs.perlins.size() * sizeof(rtd::PerlinTable)); perlin_only = 1u;
-                // ... and the tables that do not grow with the primitive count, if they are small: material, texture, transform, wrapper, light
-                const size_t small = cs.mat_a.size() * 20 + cs.xforms.size() * sizeof(rtd::Xform) + cs.wraps.size() * sizeof(rtd::Wrap) + cs.lights.size() * sizeof(rtd::Light) +
-                                     cs.textures.size() * sizeof(rtd::Texture);
-                if (small <= 4 * 1024) {
-                    sb[6] = put(cs.mat_a.data(), cs.mat_a.size() * 16); sb[7] = put(cs.mat_b.data(), cs.mat_b.size() * 4);
-                    sb[8] = put(cs.xforms.data(), cs.xforms.size() * sizeof(rtd::Xform)); sb[9] = put(cs.wraps.data(), cs.wraps.size() * sizeof(rtd::Wrap));
-                    sb[10] = put(cs.lights.data(), cs.lights.size() * sizeof(rtd::Light)); sb[11] = put(cs.textures.data(), cs.textures.size() * sizeof(rtd::Texture));
-                } else perlin_only = 2u;
-            }
+        // 7 x 8 x 4 dependent look-ups, and a wave waits for the one lane that makes it
+        if (blob.empty() && opt.perlin_lds && !cs.perlins.empty() && cs.perlins.size() * sizeof(rtd::PerlinTable) <= 16 * 1024) {
+            put(cs.perlins.data(), cs.perlins.size() * sizeof(rtd::PerlinTable)); im->perlin_only = 1u;
+            // ... and the tables that do not grow with the primitive count, if they are small: material, texture, transform, wrapper, light
+            const size_t small = cs.mat_a.size() * 20 + cs.xforms.size() * sizeof(rtd::Xform) + cs.wraps.size() * sizeof(rtd::Wrap) + cs.lights.size() * sizeof(rtd::Light) +
+                                 cs.textures.size() * sizeof(rtd::Texture);
+            if (small <= 4 * 1024) {
+                sb[6] = put(cs.mat_a.data(), cs.mat_a.size() * 16); sb[7] = put(cs.mat_b.data(), cs.mat_b.size() * 4);
+                sb[8] = put(cs.xforms.data(), cs.xforms.size() * sizeof(rtd::Xform)); sb[9] = put(cs.wraps.data(), cs.wraps.size() * sizeof(rtd::Wrap));
+                sb[10] = put(cs.lights.data(), cs.lights.size() * sizeof(rtd::Light)); sb[11] = put(cs.textures.data(), cs.textures.size() * sizeof(rtd::Texture));
+            } else im->perlin_only = 2u;
         }
     }
-    if (!blob.empty()) up(s->shade_blob, blob);
     // k_extend's primitive pass tables for LDS-resident scenes (kernels.h SceneDev::ext_blob): small ones only, inside the LDS budget
-    std::vector<unsigned char> eblob;
-    uint32_t eb[4] = {0}, eb_rect_stride = 32;
-    if (in_lds && !(cs.rects.empty() && cs.moving.empty() && cs.media.empty())) {
+    if (im->in_lds && opt.extend_lds_tables && !(cs.rects.empty() && cs.moving.empty() && cs.media.empty())) {
         // staged once per workgroup and launch (persistent waves), so size only matters against the 160 KB of the CU: the rect table as
         // it is (2 x 16 B per rect) where that fits, else without its two padding words (book-2 final scene: 2401 rects behind 91 KB of
         // records and spheres)
+        std::vector<unsigned char>& eblob = im->eblob; uint32_t* eb = im->eb;
         const size_t room = 160 * 1024 - lds_scene_bytes(cs);
         const size_t n_rects = cs.rects.size() / 2;
         for (uint32_t stride : {32u, 24u}) {
@@ -430,20 +468,39 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
             }
             eb[1] = put(cs.moving.data(), cs.moving.size() * 16);
             eb[2] = put(cs.xforms.data(), cs.xforms.size() * sizeof(rtd::Xform)); eb[3] = put(cs.media.data(), cs.media.size() * sizeof(rtd::Medium));
-            eb_rect_stride = stride;
+            im->eb_rect_stride = stride;
             if (eblob.size() <= room) break;
             eblob.clear();
         }
-        if (const char* e = getenv("RT_EXTEND_LDS_TABLES")) if (e[0] == '0') eblob.clear();
     }
-    if (!eblob.empty()) up(s->ext_blob, eblob);
-    if (r == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = set_err(ctx, RT_ERR_DEVICE, "scene upload failed");
+    im->features = scene_features(cs);
+    *out = im.release();
+    return RT_OK;
+}
+
+int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scene) {
+    *out_scene = nullptr;
+    const rtc::CompiledScene& cs = im.cs;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RtScene* s = new RtScene();
+    int r = RT_OK;
+    auto up = [&](auto& buf, const auto& vec) { if (r == RT_OK) r = upload(ctx, buf, vec); };
+    if (im.top) up(s->top_nodes, im.dn.top);
+    if (im.c16) up(s->nodes, im.n16); else up(s->nodes, im.dn.main);
+    up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
+    up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->media, cs.media);
+    up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
+    up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
+    if (!im.blob.empty()) up(s->shade_blob, im.blob);
+    if (!im.eblob.empty()) up(s->ext_blob, im.eblob);
+    if (r == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = set_err(ctx, RT_ERR_DEVICE, "scene upload failed");   // the image is the caller's: its vectors outlive this wait
     if (r != RT_OK) { rt_scene_destroy(ctx, s); return r; }
     rtk::SceneDev& d = s->dev;
+    const uint32_t* sb = im.sb; const uint32_t* eb = im.eb;
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
-    d.top_nodes = top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = top ? dn.n_top : 0u; d.n_records = c16 ? (uint32_t)n16.size() : dn.records();
-    d.oct_stride = oct_stride; d.oct_mask = oct_mask;
-    d.nodes16 = c16 ? 1u : 0u; for (int a = 0; a < 3; ++a) { d.grid_lo[a] = grid_lo[a]; d.grid_scale[a] = grid_scale[a]; }
+    d.top_nodes = im.top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = im.top ? im.dn.n_top : 0u; d.n_records = im.c16 ? (uint32_t)im.n16.size() : im.dn.records();
+    d.oct_stride = im.oct_stride; d.oct_mask = im.oct_mask;
+    d.nodes16 = im.c16 ? 1u : 0u; for (int a = 0; a < 3; ++a) { d.grid_lo[a] = im.grid_lo[a]; d.grid_scale[a] = im.grid_scale[a]; }
     d.n_prologue = (uint32_t)cs.prologue.size();
     for (uint32_t k = 0; k < rtd::MAX_PROLOGUE; ++k) d.prologue[k] = k < cs.prologue.size() ? cs.prologue[k] : 0u;
     d.n_prim_kinds = (cs.sphere_meta.empty() ? 0u : 1u) + (cs.moving_meta.empty() ? 0u : 1u) + (cs.rect_meta.empty() ? 0u : 1u) +
@@ -457,15 +514,14 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     d.textures = (const rtd::Texture*)s->textures.p; d.perlins = (const rtd::PerlinTable*)s->perlins.p;
     d.images = (const rtd::Image*)s->images.p; d.image_bytes = (const uint8_t*)s->image_bytes.p;
     d.lights = (const rtd::Light*)s->lights.p; d.n_lights = (uint32_t)cs.lights.size();
-    d.shade_blob = blob.empty() ? nullptr : (const rtd::Float4*)s->shade_blob.p; d.shade_blob_bytes = (uint32_t)blob.size();
+    d.shade_blob = im.blob.empty() ? nullptr : (const rtd::Float4*)s->shade_blob.p; d.shade_blob_bytes = (uint32_t)im.blob.size();
     d.sb_spheres = sb[0]; d.sb_sphere_meta = sb[1]; d.sb_rects = sb[2]; d.sb_rect_meta = sb[3]; d.sb_moving = sb[4]; d.sb_moving_meta = sb[5];
-    d.ext_blob = eblob.empty() ? nullptr : (const rtd::Float4*)s->ext_blob.p; d.ext_blob_bytes = (uint32_t)eblob.size();
-    d.eb_rect_stride = eb_rect_stride; d.eb_rects = eb[0]; d.eb_moving = eb[1]; d.eb_xforms = eb[2]; d.eb_media = eb[3];
-    d.sb_perlin_only = perlin_only;
+    d.ext_blob = im.eblob.empty() ? nullptr : (const rtd::Float4*)s->ext_blob.p; d.ext_blob_bytes = (uint32_t)im.eblob.size();
+    d.eb_rect_stride = im.eb_rect_stride; d.eb_rects = eb[0]; d.eb_moving = eb[1]; d.eb_xforms = eb[2]; d.eb_media = eb[3];
+    d.sb_perlin_only = im.perlin_only;
     d.sb_mat_a = sb[6]; d.sb_mat_b = sb[7]; d.sb_xforms = sb[8]; d.sb_wraps = sb[9]; d.sb_lights = sb[10]; d.sb_textures = sb[11];
-    const uint32_t f = scene_features(cs);
-    s->features = f;
-    s->in_lds = in_lds; s->lds_bytes = lds_scene_bytes(cs);
+    s->features = im.features;
+    s->in_lds = im.in_lds; s->lds_bytes = lds_scene_bytes(cs);
     s->bg_mode = cs.background_mode; for (int i = 0; i < 3; ++i) s->bg[i] = cs.background[i];
     s->n_nodes = cs.nodes.size();
     s->n_prims = cs.sphere_meta.size() + cs.moving_meta.size() + cs.rect_meta.size() + cs.tri_meta.size() + cs.media.size();
@@ -474,6 +530,21 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) {
     *out_scene = s;
     return RT_OK;
 }
+
+extern "C" {
+
+int rt_scene_upload_ex(RtCtx* ctx, const RtSceneDesc* desc, const RtUploadOptions* options, RtScene** out_scene) {
+    if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
+    if (!desc || !out_scene) return set_err(ctx, RT_ERR_INVALID, "desc / out_scene is null");
+    *out_scene = nullptr;
+    SceneImage* im = nullptr; std::string err;
+    const int rc = scene_image_build(desc, options, &im, err);
+    if (rc != RT_OK) return set_err(ctx, rc, err);
+    const int r = scene_image_upload(ctx, *im, out_scene);
+    scene_image_free(im);
+    return r;
+}
+int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) { return rt_scene_upload_ex(ctx, desc, nullptr, out_scene); }
 
 int rt_scene_destroy(RtCtx* ctx, RtScene* s) {
     if (!s) return RT_OK;
@@ -635,8 +706,8 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     // HBM (config-5 stand-in, 2048^2 x 32, near-first record orders): 2^18 126.0 ms, 2^20 126.2, 2^21 131.7, 2^22 143.4, 2^24 193.8. (With ONE
     // record order a k_extend launch of that scene did not get shorter than 1.5-2 ms however few rays it carried — the longest far-first walk
     // of the launch — and 2^21 was the best hand-over: 185.9 ms against 211.5 at 2^18.)
-    uint32_t drain_at = 1u << 18;
-    if (const char* e = getenv("RT_DRAIN_AT")) drain_at = (uint32_t)std::strtoul(e, nullptr, 10);
+    uint32_t drain_at = prm->tail_paths ? prm->tail_paths : (1u << 18);          // RtParams.tail_paths (1 = never: a pool holds 8 queues of >= 1 path)
+    if (const char* e = getenv("RT_DRAIN_AT")) drain_at = (uint32_t)std::strtoul(e, nullptr, 10);   // scripts/ only
     if (prm->flags & RT_FLAG_FUSED) drain_at = 0xFFFFFFFFu;
     uint32_t launched = 0, drained = 0;
     std::vector<uint32_t> iter_live;     // RT_DEBUG_ITER=1 (with RT_FLAG_TIMING): the host's bound of the largest queue at every iteration
@@ -754,10 +825,11 @@ static uint32_t scene_features(const rtc::CompiledScene& cs) {
     return f;
 }
 
-int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out) {
+int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out) { return rt_scene_compile_info_ex(desc, nullptr, out); }
+int rt_scene_compile_info_ex(const RtSceneDesc* desc, const RtUploadOptions* options, RtCompileInfo* out) {
     if (!desc || !out) return set_err(nullptr, RT_ERR_INVALID, "null argument");
     rtc::CompiledScene cs;
-    const int rc = rtc::compile_scene(*desc, cs);
+    const int rc = rtc::compile_scene(*desc, resolve_options(options).compile, cs);
     if (rc != RT_OK) return set_err(nullptr, rc, "scene: " + cs.error);
     out->n_nodes = cs.nodes.size(); out->n_box_nodes = cs.n_box_nodes; out->n_spheres = cs.sphere_meta.size(); out->n_moving = cs.moving_meta.size();
     out->n_rects = cs.rect_meta.size(); out->n_tris = cs.tri_meta.size(); out->n_media = cs.media.size(); out->n_xforms = cs.xforms.size();
@@ -810,14 +882,24 @@ int rt_scene_top_layout_check(const RtSceneDesc* desc, uint32_t max_top, uint64_
 }
 
 int rt_scene_compile_dump(const RtSceneDesc* desc, void* nodes, uint64_t cap_nodes, float* spheres, uint32_t* sphere_meta, uint64_t cap_spheres) {
+    return rt_scene_compile_dump_ex(desc, nullptr, nodes, cap_nodes, spheres, sphere_meta, cap_spheres);
+}
+int rt_scene_compile_dump_ex(const RtSceneDesc* desc, const RtUploadOptions* options, void* nodes, uint64_t cap_nodes, float* spheres, uint32_t* sphere_meta,
+                             uint64_t cap_spheres) {
     if (!desc) return set_err(nullptr, RT_ERR_INVALID, "null argument");
     rtc::CompiledScene cs;
-    const int rc = rtc::compile_scene(*desc, cs);
+    const int rc = rtc::compile_scene(*desc, resolve_options(options).compile, cs);
     if (rc != RT_OK) return set_err(nullptr, rc, "scene: " + cs.error);
     if ((nodes && cap_nodes < cs.nodes.size()) || ((spheres || sphere_meta) && cap_spheres < cs.sphere_meta.size())) return set_err(nullptr, RT_ERR_INVALID, "capacity too small");
     if (nodes) std::memcpy(nodes, cs.nodes.data(), cs.nodes.size() * sizeof(rtd::Node));
     if (spheres) std::memcpy(spheres, cs.spheres.data(), cs.spheres.size() * sizeof(rtd::Float4));
     if (sphere_meta) std::memcpy(sphere_meta, cs.sphere_meta.data(), cs.sphere_meta.size() * 4);
+    return RT_OK;
+}
+
+int rt_test_fail_next_renders(RtCtx* ctx, uint32_t n) {
+    if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
+    ctx->fail_renders = n;
     return RT_OK;
 }
 

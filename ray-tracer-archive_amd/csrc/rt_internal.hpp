@@ -41,6 +41,10 @@ struct RtCtx {
     // one-process-per-GPU gather (rt_comm_init_rank): an RCCL communicator, opaque here (rt_multi.cpp)
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;
     rti::DevBuf shard_tmp;                       // this rank's shard before it is sent
+    rti::DevBuf comm_words;                      // status words of the agreement that precedes every exchange (rt_multi.cpp agree_on_status)
+    uint32_t* h_words = nullptr;                 // pinned: the same words on the host
+    hipEvent_t ev_gather[2] = {nullptr, nullptr}; // brackets the exchange (RtStats.gather_ms); made at the first gather, kept
+    uint32_t fail_renders = 0;                   // rt_test_fail_next_renders: renders still to fail (fault injection for the failure-path tests)
 };
 
 struct RtScene {
@@ -79,8 +83,16 @@ inline int make_tiling(const RtParams& p, Tiling& t) {
 }
 
 int validate_params(RtCtx* ctx, const RtParams* p);
+// A scene compiled and laid out for the device, still on the host (rt_api.cpp): built once, uploaded to one device or to n
+struct UploadOpts;
+struct SceneImage;
+int scene_image_build(const RtSceneDesc* desc, const RtUploadOptions* options, SceneImage** out, std::string& err);
+int scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scene);
+void scene_image_free(SceneImage* im);
 // rt_render_device without the argument checks; drains the stream on failure
 int render_checked(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, void* d_out, RtStats* stats);
 void comm_release(RtCtx* ctx);   // rt_multi.cpp: destroys ctx->comm if any
+// mapped copies of the ROCm runtime libraries (rt_multi.cpp): false + message when one of them is mapped twice
+bool runtime_libraries_ok(std::string& listing, std::string& why);
 
 }  // namespace rti

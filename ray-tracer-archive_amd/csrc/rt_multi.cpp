@@ -9,6 +9,7 @@
 // RCCL is loaded with dlopen at the first multi-GPU call (librccl.so.1 is a 570 MB library the single-GPU path never needs; a
 // process that already holds it — PyTorch does — shares that copy).
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 #include <chrono>
@@ -39,15 +40,39 @@ struct Rccl {
 Rccl g_rccl;
 std::once_flag g_rccl_once;
 
+// Mapped objects of the process whose file name starts with `stem` (dl_iterate_phdr), each path once.
+struct MapScan { const char* stem; std::vector<std::string> paths; };
+int map_scan_cb(struct dl_phdr_info* info, size_t, void* data) {
+    MapScan* m = (MapScan*)data;
+    if (!info->dlpi_name || !info->dlpi_name[0]) return 0;
+    const char* base = std::strrchr(info->dlpi_name, '/');
+    base = base ? base + 1 : info->dlpi_name;
+    if (std::strncmp(base, m->stem, std::strlen(m->stem)) != 0) return 0;
+    for (const std::string& p : m->paths) if (p == info->dlpi_name) return 0;
+    m->paths.push_back(info->dlpi_name);
+    return 0;
+}
+std::vector<std::string> mapped(const char* stem) { MapScan m{stem, {}}; dl_iterate_phdr(map_scan_cb, &m); return m.paths; }
+
 const Rccl* rccl() {
     std::call_once(g_rccl_once, [] {
-        // a copy the process already holds (PyTorch links its own librccl.so.1) is shared, never doubled; RT_RCCL_LIB overrides
-        const char* env = getenv("RT_RCCL_LIB");
-        if (env && env[0]) g_rccl.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-        if (!g_rccl.handle) g_rccl.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) { if (g_rccl.handle) break; g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
-        if (!g_rccl.handle) { g_rccl.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
+        // ONE librccl per process. PyTorch bundles its own (torch/lib/librccl.so, soname librccl.so.1) and a process that ends up with that
+        // copy AND /opt/rocm's holds two RCCLs over two HIP runtimes — the round-2 abort ("double free or corruption" at exit, DESIGN.md
+        // section 6). So: a copy that is already mapped is the copy (opened again by its own path, which only takes a reference); two mapped
+        // copies are refused; only a process without any gets one loaded by name. RT_RCCL_LIB names a file for the last case.
+        const std::vector<std::string> have = mapped("librccl.so");
+        if (have.size() > 1) { g_rccl.error = "two copies of librccl are mapped in this process (" + have[0] + ", " + have[1] + "): refusing to use either"; return; }
+        if (have.size() == 1) g_rccl.handle = dlopen(have[0].c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+        else {
+            const char* env = getenv("RT_RCCL_LIB");
+            if (env && env[0]) g_rccl.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* n : names) { if (g_rccl.handle) break; g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
+            // the copy just loaded must sit on the HIP runtime this library runs on, not bring a second one
+            std::string listing, why;
+            if (g_rccl.handle && !runtime_libraries_ok(listing, why)) { g_rccl.error = "loading librccl mapped a second ROCm runtime: " + why; return; }
+        }
+        if (!g_rccl.handle) { const char* de = dlerror(); g_rccl.error = std::string("cannot load librccl: ") + (de ? de : "?"); return; }
         auto sym = [&](const char* n) { void* p = dlsym(g_rccl.handle, n); if (!p && g_rccl.error.empty()) g_rccl.error = std::string("librccl lacks ") + n; return p; };
         g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
         g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
@@ -77,7 +102,67 @@ int shard_geom(const RtParams& prm, uint32_t world, ShardGeom& g) {
     return RT_OK;
 }
 
-// One rank's part of a sharded render: render shard `rank` of `world`, optional write_color on the shard, exchange, and on the
+// ---- failure agreement: before any shard moves, every rank learns whether EVERY rank has a shard to give -------------------------------
+// Each peer sends one status word to the root and gets the verdict word back: two exchanges of 4 bytes per peer on the context's stream
+// (tens of microseconds beside a frame of tens of milliseconds). Verdict 0 = go; else 1 + the lowest rank that failed. Without it a
+// rank whose render failed (out of memory, a HIP error) returned early while the root had already posted ncclRecv for its shard and then
+// waited in hipStreamSynchronize for ever (round-2 ADVICE; the ABI promises error codes, never hangs). Now every rank returns: the one
+// that failed its own error, the others RT_ERR_PEER naming it. Only a failure of the COMMUNICATOR itself (an RCCL error inside this
+// function) is beyond agreement; it comes back as RT_ERR_DEVICE.
+constexpr int kMaxWorld = 64;
+int agree_on_status(RtCtx* ctx, const Rccl* R, int my_status, int* failed_rank) {
+    *failed_rank = -1;
+    const int world = ctx->comm_world, rank = ctx->comm_rank;
+    if (world < 2) { if (my_status != RT_OK) *failed_rank = rank; return RT_OK; }
+    if (world > kMaxWorld || !ctx->comm_words.p || !ctx->h_words) return set_err(ctx, RT_ERR_INVALID, "communicator without its status words (rt_comm_init_rank)");
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    uint32_t* dev = (uint32_t*)ctx->comm_words.p;   // [0] this rank's word, [1] the verdict, [2 + r] rank r's word on the root
+    uint32_t* host = ctx->h_words;
+    host[0] = my_status != RT_OK ? 1u : 0u;
+    if (rank == 0) {
+        NCCL_TRY(ctx, R->GroupStart());
+        for (int r = 1; r < world; ++r) {
+            const ncclResult_t q = R->Recv(dev + 2 + r, 1, ncclUint32, r, comm, ctx->stream);
+            if (q != ncclSuccess) { (void)R->GroupEnd(); return set_err(ctx, RT_ERR_DEVICE, std::string("ncclRecv (status): ") + R->GetErrorString(q)); }
+        }
+        NCCL_TRY(ctx, R->GroupEnd());
+        HIP_TRY(ctx, hipMemcpyAsync(host + 2, dev + 2, sizeof(uint32_t) * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        host[2] = host[0];
+        uint32_t verdict = 0u;
+        for (int r = world - 1; r >= 0; --r) if (host[2 + r] != 0u) verdict = (uint32_t)r + 1u;
+        host[1] = verdict;
+        HIP_TRY(ctx, hipMemcpyAsync(dev + 1, host + 1, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        NCCL_TRY(ctx, R->GroupStart());
+        for (int r = 1; r < world; ++r) {
+            const ncclResult_t q = R->Send(dev + 1, 1, ncclUint32, r, comm, ctx->stream);
+            if (q != ncclSuccess) { (void)R->GroupEnd(); return set_err(ctx, RT_ERR_DEVICE, std::string("ncclSend (verdict): ") + R->GetErrorString(q)); }
+        }
+        NCCL_TRY(ctx, R->GroupEnd());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (verdict != 0u) *failed_rank = (int)verdict - 1;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(dev, host, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        NCCL_TRY(ctx, R->Send(dev, 1, ncclUint32, 0, comm, ctx->stream));
+        NCCL_TRY(ctx, R->Recv(dev + 1, 1, ncclUint32, 0, comm, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(host + 1, dev + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (host[1] != 0u) *failed_rank = (int)host[1] - 1;
+    }
+    return RT_OK;
+}
+// what the verdict means for this rank: its own error if it failed, RT_ERR_PEER naming the first failed rank otherwise
+int called_off(RtCtx* ctx, int my_status, const std::string& my_error, int failed_rank) {
+    if (my_status != RT_OK) { ctx->err = my_error; g_last_error = my_error; return my_status; }
+    return set_err(ctx, RT_ERR_PEER, "rank " + std::to_string(failed_rank) + " failed its part of the render: the exchange was called off on every rank");
+}
+int attach_comm(RtCtx* ctx, void* comm, int rank, int world) {
+    HIP_TRY(ctx, ctx->comm_words.ensure(sizeof(uint32_t) * (size_t)(kMaxWorld + 2)));
+    ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
+    return RT_OK;
+}
+
+// One rank's part of a sharded render: render shard `rank` of `world`, optional write_color on the shard, agreement, exchange, and on the
 // root the untile kernel into `frame_device`. The same code serves one-process-per-GPU (rt_render_gather) and the threads of
 // rt_render_multi (one communicator per device from ncclCommInitAll).
 int render_gather_rank(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm_in, uint32_t kind, void* frame_device, RtStats* stats) {
@@ -88,26 +173,20 @@ int render_gather_rank(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         if (!R) return set_err(ctx, RT_ERR_DEVICE, g_rccl.error);
         if (!ctx->comm) return set_err(ctx, RT_ERR_INVALID, "no communicator on this context (rt_comm_init_rank)");
     }
+    // argument errors are the same on every rank (same params, same call): they return before anything is posted
     if (kind > RT_OUT_RGB8) return set_err(ctx, RT_ERR_INVALID, "bad output kind");
     RtParams prm = *prm_in;
     prm.shard_index = (uint32_t)rank; prm.shard_count = (uint32_t)world;
     if (prm.tile_size == 0) prm.tile_size = 32;
     const int v = validate_params(ctx, &prm); if (v != RT_OK) return v;
-    if (rank == 0 && !frame_device) return set_err(ctx, RT_ERR_INVALID, "rank 0 needs a frame buffer");
     ShardGeom g; if (shard_geom(prm, (uint32_t)world, g) != RT_OK) return set_err(ctx, RT_ERR_INVALID, "bad tiling parameters");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t elem = kind == RT_OUT_RGB8 ? 1 : 4;
     const size_t shard_elems = (size_t)g.per_shard_px * 3;
     const auto t0 = std::chrono::steady_clock::now();
-    // f32 shard of this rank; the root's lives at slot 0 of the gather buffer when the exchange is f32
-    HIP_TRY(ctx, ctx->shard_tmp.ensure(shard_elems * 4 + (kind == RT_OUT_RGB8 ? shard_elems : 0)));
-    float* shard_f32 = (float*)ctx->shard_tmp.p;
-    uint8_t* shard_u8 = (uint8_t*)ctx->shard_tmp.p + shard_elems * 4;
-    void* gather = nullptr;
-    if (rank == 0 && world > 1) { HIP_TRY(ctx, ctx->out_tmp.ensure(shard_elems * elem * (size_t)world)); gather = ctx->out_tmp.p; }
-    void* mine = shard_f32;                                      // what this rank contributes, in the exchange's element type
     if (world == 1) {
         // one GPU: no tiles to move. f32: render straight into the caller's frame; u8: render, then write_color into it
+        if (!frame_device) return set_err(ctx, RT_ERR_INVALID, "rank 0 needs a frame buffer");
         prm.shard_count = 1; prm.shard_index = 0;
         if (kind == RT_OUT_RGB_SUM_F32) return render_checked(ctx, scene, cam, &prm, frame_device, stats);
         uint64_t n = 0; rt_output_floats(&prm, &n);
@@ -119,14 +198,30 @@ int render_gather_rank(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         if (stats) { stats->n_devices = 1; stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
         return RT_OK;
     }
+    // ---- this rank's part; a failure from here on is NOT returned before the other ranks know of it ----
+    int my = RT_OK; std::string my_error;
+    auto fail = [&](int code, const std::string& msg) { if (my == RT_OK) { my = code; my_error = msg; } };
+    if (rank == 0 && !frame_device) fail(RT_ERR_INVALID, "rank 0 needs a frame buffer");
+    // f32 shard of this rank; the root's lives at slot 0 of the gather buffer when the exchange is f32
+    if (ctx->shard_tmp.ensure(shard_elems * 4 + (kind == RT_OUT_RGB8 ? shard_elems : 0)) != hipSuccess) fail(RT_ERR_OOM, "out of device memory for this rank's shard");
+    float* shard_f32 = (float*)ctx->shard_tmp.p;
+    uint8_t* shard_u8 = (uint8_t*)ctx->shard_tmp.p + shard_elems * 4;
+    void* gather = nullptr;
+    if (rank == 0) { if (ctx->out_tmp.ensure(shard_elems * elem * (size_t)world) != hipSuccess) fail(RT_ERR_OOM, "out of device memory for the gathered shards"); gather = ctx->out_tmp.p; }
+    void* mine = shard_f32;                                      // what this rank contributes, in the exchange's element type
     if (rank == 0 && kind == RT_OUT_RGB_SUM_F32) mine = gather;  // slot 0
-    {
+    if (my == RT_OK) {
         const int r = render_checked(ctx, scene, cam, &prm, kind == RT_OUT_RGB_SUM_F32 ? mine : (void*)shard_f32, stats);
-        if (r != RT_OK) return r;
+        if (r != RT_OK) fail(r, ctx->err);
     }
-    hipEvent_t e0, e1;
-    HIP_TRY(ctx, hipEventCreate(&e0)); HIP_TRY(ctx, hipEventCreate(&e1));
-    struct Ev { hipEvent_t a, b; ~Ev() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } ev{e0, e1};
+    {
+        int failed = -1;
+        const int a = agree_on_status(ctx, R, my, &failed);
+        if (a != RT_OK) return a;
+        if (failed >= 0) return called_off(ctx, my, my_error, failed);
+    }
+    if (!ctx->ev_gather[0]) { HIP_TRY(ctx, hipEventCreate(&ctx->ev_gather[0])); HIP_TRY(ctx, hipEventCreate(&ctx->ev_gather[1])); }
+    hipEvent_t e0 = ctx->ev_gather[0], e1 = ctx->ev_gather[1];
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
     if (kind == RT_OUT_RGB8) {
         // write_color on the shard (an elementwise map over its compact tile buffer; clipped pixels are 0 and stay 0)
@@ -163,6 +258,22 @@ int render_gather_rank(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
 
 }  // namespace
 
+bool rti::runtime_libraries_ok(std::string& listing, std::string& why) {
+    listing.clear(); why.clear();
+    bool ok = true;
+    for (const char* stem : {"libamdhip64.so", "libhsa-runtime64.so", "librccl.so"}) {
+        const std::vector<std::string> have = mapped(stem);
+        for (const std::string& p : have) listing += p + "\n";
+        if (have.size() > 1 && why.empty()) {
+            ok = false;
+            why = std::string("two copies of ") + stem + " are mapped in this process (" + have[0] + ", " + have[1] + "): two ROCm runtimes with separate device state, "
+                  "which ends in heap corruption at exit. PyTorch bundles its own copies under other file names; load it BEFORE this library (its copies carry the "
+                  "system's sonames and are then shared)";
+        }
+    }
+    return ok;
+}
+
 void rti::comm_release(RtCtx* ctx) {
     if (ctx && ctx->comm) { const Rccl* R = rccl(); if (R) (void)R->CommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; ctx->comm_world = 1; ctx->comm_rank = 0; }
 }
@@ -176,6 +287,13 @@ struct RtMultiCtx {
 struct RtMultiScene { std::vector<RtScene*> scene; };
 
 extern "C" {
+
+int rt_runtime_libraries(char* out, uint64_t cap) {
+    std::string listing, why;
+    const bool ok = runtime_libraries_ok(listing, why);
+    if (out && cap) { const size_t n = std::min<size_t>(listing.size(), (size_t)cap - 1); std::memcpy(out, listing.data(), n); out[n] = 0; }
+    return ok ? RT_OK : set_err(nullptr, RT_ERR_DEVICE, why);
+}
 
 int rt_comm_unique_id(uint8_t* id_out) {
     if (!id_out) return set_err(nullptr, RT_ERR_INVALID, "id_out is null");
@@ -195,10 +313,10 @@ int rt_comm_init_rank(RtCtx* ctx, const uint8_t* id_in, int rank, int world) {
     comm_release(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ncclUniqueId id; std::memcpy(id.internal, id_in, RT_COMM_ID_BYTES);
+    if (world > kMaxWorld) return set_err(ctx, RT_ERR_INVALID, "world larger than 64");
     ncclComm_t comm = nullptr;
     NCCL_TRY(ctx, R->CommInitRank(&comm, world, id, rank));
-    ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
-    return RT_OK;
+    return attach_comm(ctx, comm, rank, world);
 }
 
 int rt_comm_selftest(RtCtx* ctx) {
@@ -274,7 +392,10 @@ int rt_ctx_create_multi(const int* device_ids, int n, RtMultiCtx** out) {
     std::vector<ncclComm_t> comms((size_t)n, nullptr);
     const ncclResult_t q = R->CommInitAll(comms.data(), n, device_ids);   // single process: one communicator per device
     if (q != ncclSuccess) { rt_ctx_destroy_multi(m); return set_err(nullptr, RT_ERR_DEVICE, std::string("ncclCommInitAll: ") + R->GetErrorString(q)); }
-    for (int i = 0; i < n; ++i) { m->ctx[i]->comm = comms[i]; m->ctx[i]->comm_rank = i; m->ctx[i]->comm_world = n; }
+    for (int i = 0; i < n; ++i) {
+        const int r = attach_comm(m->ctx[i], comms[i], i, n);
+        if (r != RT_OK) { const std::string why = m->ctx[i]->err; for (int k = i + 1; k < n; ++k) (void)R->CommDestroy(comms[k]); rt_ctx_destroy_multi(m); return set_err(nullptr, r, why); }
+    }
     *out = m;
     return RT_OK;
 }
@@ -286,19 +407,25 @@ int rt_scene_destroy_multi(RtMultiCtx* m, RtMultiScene* s) {
     return RT_OK;
 }
 
-int rt_scene_upload_multi(RtMultiCtx* m, const RtSceneDesc* desc, RtMultiScene** out) {
+int rt_scene_upload_multi_ex(RtMultiCtx* m, const RtSceneDesc* desc, const RtUploadOptions* options, RtMultiScene** out) {
     if (!m || !desc || !out) return set_err(nullptr, RT_ERR_INVALID, "null argument");
     *out = nullptr;
+    // compiled and laid out ONCE (the 1.26 M-primitive tree of config 5 takes seconds to build), then copied to every device
+    SceneImage* im = nullptr; std::string err;
+    const int rc = scene_image_build(desc, options, &im, err);
+    if (rc != RT_OK) { m->err = err; return set_err(nullptr, rc, err); }
     RtMultiScene* s = new RtMultiScene();
     for (RtCtx* c : m->ctx) {
         RtScene* sc = nullptr;
-        const int r = rt_scene_upload(c, desc, &sc);
-        if (r != RT_OK) { m->err = c->err; rt_scene_destroy_multi(m, s); return r; }
+        const int r = scene_image_upload(c, *im, &sc);
+        if (r != RT_OK) { m->err = c->err; scene_image_free(im); rt_scene_destroy_multi(m, s); return set_err(nullptr, r, m->err); }
         s->scene.push_back(sc);
     }
+    scene_image_free(im);
     *out = s;
     return RT_OK;
 }
+int rt_scene_upload_multi(RtMultiCtx* m, const RtSceneDesc* desc, RtMultiScene** out) { return rt_scene_upload_multi_ex(m, desc, nullptr, out); }
 
 static int render_multi(RtMultiCtx* m, const RtMultiScene* s, const RtCamera* cam, const RtParams* prm, uint32_t kind, void* host_out, RtStats* stats) {
     if (!m) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
@@ -321,7 +448,10 @@ static int render_multi(RtMultiCtx* m, const RtMultiScene* s, const RtCamera* ca
     for (int i = 1; i < n; ++i) th.emplace_back([&, i] { rc[i] = render_gather_rank(m->ctx[i], s->scene[i], cam, prm, kind, nullptr, &st[i]); });
     rc[0] = render_gather_rank(root, s->scene[0], cam, prm, kind, m->frame.p, &st[0]);
     for (auto& t : th) t.join();
-    for (int i = 0; i < n; ++i) if (rc[i] != RT_OK) { m->err = "device " + std::to_string(m->ctx[i]->device) + ": " + m->ctx[i]->err; return set_err(nullptr, rc[i], m->err); }
+    // the device that failed its own part speaks first (the others only report RT_ERR_PEER, "rank k failed")
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < n; ++i)
+            if (rc[i] != RT_OK && (pass == 1 || rc[i] != RT_ERR_PEER)) { m->err = "device " + std::to_string(m->ctx[i]->device) + ": " + m->ctx[i]->err; return set_err(nullptr, rc[i], m->err); }
     // frame -> host (through pinned memory when it could be had)
     (void)hipSetDevice(root->device);
     hipError_t e = hipSuccess;

@@ -768,7 +768,7 @@ struct Compiler {
 
 }  // namespace
 
-int compile_scene(const RtSceneDesc& desc, CompiledScene& out) {
+int compile_scene(const RtSceneDesc& desc, const CompileOptions& opt, CompiledScene& out) {
     out = CompiledScene();
     if (desc.abi_version != RT_ABI_VERSION) { out.error = "RtSceneDesc.abi_version mismatch"; return RT_ERR_INVALID; }
     if (!desc.hittables || desc.n_hittables == 0) { out.error = "scene has no hittables"; return RT_ERR_INVALID; }
@@ -781,11 +781,9 @@ int compile_scene(const RtSceneDesc& desc, CompiledScene& out) {
     // (Cornell 23 -> 33 ms, Cornell smoke 52 -> 60 ms): there the members stay as the reference has them.
     uint64_t bvh_members = 0;
     for (uint64_t i = 0; i < desc.n_hittables; ++i) if (desc.hittables[i].kind == RT_HIT_BVH && desc.hittables[i].n_children > 0) bvh_members += (uint64_t)desc.hittables[i].n_children;
-    c.cull_lists = bvh_members >= 32;
-    if (const char* e = getenv("RT_LIST_CULL")) c.cull_lists = e[0] == '2' ? true : (c.cull_lists && e[0] != '0');   // 0: never, 2: always (tests)
-    c.box_pair_members = desc.n_hittables < 8192;      // scenes of that size are LDS-resident (rt_api.cpp: 144 KB of records and spheres)
-    if (const char* e = getenv("RT_PAIR_BOXES")) c.box_pair_members = e[0] == '2' ? true : (c.box_pair_members && e[0] != '0');   // 0: never, 2: always
-    if (const char* e = getenv("RT_LIST_PARK_COST")) c.park_cost = std::max(0.0, std::atof(e));
+    c.cull_lists = opt.cull_lists < 0 ? bvh_members >= 32 : opt.cull_lists != 0;
+    c.box_pair_members = opt.member_boxes < 0 ? desc.n_hittables < 8192 : opt.member_boxes != 0;      // scenes of that size are LDS-resident (rt_api.cpp: 144 KB of records and spheres)
+    c.park_cost = std::max(0.0, opt.park_cost);
     out.xforms.push_back(rtd::Xform{0.f, 1.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
     out.wraps.push_back(rtd::Wrap{});
     c.compile_materials();
@@ -802,7 +800,7 @@ int compile_scene(const RtSceneDesc& desc, CompiledScene& out) {
     if (out.xforms.size() > 255) { out.error = "more than 255 distinct instance transforms must be flattened by the caller"; return RT_ERR_UNSUPPORTED; }
     c.merge_runs();
     c.fold_box_leaf();
-    if (const char* e = getenv("RT_LEAF_COLLAPSE")) { const uint32_t k = (uint32_t)std::strtoul(e, nullptr, 10); if (k > 1) c.collapse_small_subtrees(k); }
+    if (opt.leaf_collapse > 1) c.collapse_small_subtrees(opt.leaf_collapse);
     c.compile_lights();
     if (!c.ok()) return RT_ERR_INVALID;
     out.background_mode = desc.background_mode;

@@ -30,7 +30,16 @@ struct CompiledScene {
     std::string error;
 };
 
+// Layout choices of the compiler (include/rt_hip.h RtUploadOptions); none changes a hit.
+struct CompileOptions {
+    int cull_lists = -1;        // HittableList members behind culling boxes: -1 = when the scene holds a BVH of >= 32 members, 0 = never (the reference's walk), 1 = always
+    int member_boxes = -1;      // a sphere of a span-2 BVH node / SAH leaf gets a box of its own: -1 = in LDS-sized scenes, 0 = never (bvh.rs:99-107), 1 = always
+    double park_cost = 6.0;     // a stop of the walk at a leaf, in primitive tests (grouping of culled list members)
+    uint32_t leaf_collapse = 0; // a box node whose subtree is <= n primitives of one kind becomes a leaf (0/1: off)
+};
+
 // Returns RT_OK or a negative RtStatus; `out.error` explains.
-int compile_scene(const RtSceneDesc& desc, CompiledScene& out);
+int compile_scene(const RtSceneDesc& desc, const CompileOptions& opt, CompiledScene& out);
+inline int compile_scene(const RtSceneDesc& desc, CompiledScene& out) { return compile_scene(desc, CompileOptions(), out); }
 
 }  // namespace rtc

@@ -19,7 +19,7 @@ from . import api
 def shard_params(base, rank, world, tile_size=32):
     """RtParams for `rank` of `world` (same image, same seed: the picture does not depend on world)."""
     return api.make_params(base.width, base.height, base.samples_per_pixel, base.max_depth, base.seed, base.nan_policy, base.flags,
-                           tile_size, rank, world, base.pool_slots)
+                           tile_size, rank, world, base.pool_slots, base.tail_paths)
 
 
 def shard_floats(base, world, tile_size=32):

@@ -30,7 +30,9 @@ int rt_host_scene_create(const char* name, uint64_t scene_seed, uint64_t arg0, u
     else if (n == "book1_ref") s->recipe = rt::random_scene(scene_seed, 1, true);
     else if (n == "cornell") s->recipe = rt::cornell_box();
     else if (n == "cornell_smoke") s->recipe = rt::cornell_smoke();
+    else if (n == "cornell_smoke_lit") s->recipe = rt::cornell_smoke(true);
     else if (n == "final") s->recipe = rt::final_scene(scene_seed, image, image_w, image_h);
+    else if (n == "final_lit") s->recipe = rt::final_scene(scene_seed, image, image_w, image_h, true);
     else if (n == "big" || n == "big_sah") s->recipe = rt::big_scene(scene_seed, (uint32_t)arg0, (uint32_t)arg1);
     else if (n == "book1_sah") s->recipe = rt::random_scene(scene_seed, 0, true);
     // BASELINE config 5 with an IMPORTED mesh: "big_obj:<path>" / "big_obj_sah:<path>" = arg0 random spheres + the OBJ file's triangles

@@ -332,8 +332,10 @@ inline SceneRecipe cornell_box() {
     return r;
 }
 
-// main.rs:435-519 cornell_smoke (commented in the reference)
-inline SceneRecipe cornell_smoke() {
+// main.rs:435-519 cornell_smoke (commented in the reference). `lit`: the light wrapped in FlipFace as cornell_box does (main.rs:359-361) —
+// under HEAD's DiffuseLight::emitted (material.rs:184-190, front face only) the literal scene's light faces the ceiling and the room
+// stays dark; the lit twin is the parity frame that carries signal. Nothing else differs.
+inline SceneRecipe cornell_smoke(bool lit = false) {
     HittableList objects;
     auto red = Lambertian::construct(Color3(0.65, 0.05, 0.05));
     auto white = Lambertian::construct(Color3(0.73, 0.73, 0.73));
@@ -341,7 +343,8 @@ inline SceneRecipe cornell_smoke() {
     auto light = DiffuseLight::construct_color(Color3(7, 7, 7));
     objects.add(YzRect::construct(0, 555, 0, 555, 555, green));
     objects.add(YzRect::construct(0, 555, 0, 555, 0, red));
-    objects.add(XzRect::construct(113, 443, 127, 432, 554, light));
+    if (lit) objects.add(FlipFace::construct(XzRect::construct(113, 443, 127, 432, 554, light)));
+    else objects.add(XzRect::construct(113, 443, 127, 432, 554, light));
     objects.add(XzRect::construct(0, 555, 0, 555, 555, white));
     objects.add(XzRect::construct(0, 555, 0, 555, 0, white));
     objects.add(XyRect::construct(0, 555, 0, 555, 555, white));
@@ -359,8 +362,10 @@ inline SceneRecipe cornell_smoke() {
 }
 
 // main.rs:521-649 final_scene (book 2; commented in the reference). `earth` = decoded earthmap.jpg
-// (main.rs:601-612) or nullptr (ImageTexture then returns cyan, texture.rs:118-120).
-inline SceneRecipe final_scene(uint64_t scene_seed, const uint8_t* earth, uint32_t earth_w, uint32_t earth_h) {
+// (main.rs:601-612) or nullptr (ImageTexture then returns cyan, texture.rs:118-120). `lit`: the light wrapped in FlipFace (as
+// main.rs:359-361 does for Cornell) so that it shines DOWN under HEAD's front-face-only DiffuseLight (material.rs:184-190); the literal
+// scene (main.rs:548-553) is nearly black. Nothing else differs, the scene RNG draws are the same.
+inline SceneRecipe final_scene(uint64_t scene_seed, const uint8_t* earth, uint32_t earth_w, uint32_t earth_h, bool lit = false) {
     SceneRng g(scene_seed);
     HittableList boxes1;
     auto ground = Lambertian::construct(Color3(0.48, 0.83, 0.53));
@@ -374,7 +379,8 @@ inline SceneRecipe final_scene(uint64_t scene_seed, const uint8_t* earth, uint32
         }
     HittableList objects;
     objects.add(BVHNode::construct2(boxes1, 0.0, 1.0));
-    objects.add(XzRect::construct(123, 423, 147, 412, 554, DiffuseLight::construct_color(Color3(7, 7, 7))));
+    if (lit) objects.add(FlipFace::construct(XzRect::construct(123, 423, 147, 412, 554, DiffuseLight::construct_color(Color3(7, 7, 7)))));
+    else objects.add(XzRect::construct(123, 423, 147, 412, 554, DiffuseLight::construct_color(Color3(7, 7, 7))));
     const Point3 center1(400, 400, 200), center2 = center1 + Vec3(30, 0, 0);
     objects.add(MovingSphere::construct(center1, center2, 0.0, 1.0, 50.0, Lambertian::construct(Color3(0.7, 0.3, 0.1))));
     objects.add(Sphere::construct(Point3(260, 150, 45), 50.0, Dielectric::construct(1.5)));

@@ -65,28 +65,3 @@ def record_metric(**kw):
             f.write(json.dumps(kw) + "\n")
     except OSError:
         pass
-
-
-import contextlib
-
-
-@contextlib.contextmanager
-def reference_shaped_lists():
-    """Scenes uploaded inside this block keep every HittableList member in front of every ray, as hittable_list.rs:33-50 does
-    (RT_LIST_CULL=0): the device's test counters then count what the reference's would. The default layout (culling boxes around
-    list members, every-ray members tested when a walk begins) gives the same picture with fewer tests."""
-    # ... and RT_OCTANT_ORDER=0: one record array in the reference's child order (left, then right, bvh.rs:134-143) instead of one array
-    # per direction octant ordered near-first (scenes in HBM)
-    # ... and RT_PAIR_BOXES=0: the two members of a span-2 BVH node without boxes of their own (bvh.rs:99-107 tests both objects directly)
-    names = ("RT_LIST_CULL", "RT_OCTANT_ORDER", "RT_PAIR_BOXES")
-    old = {k: os.environ.get(k) for k in names}
-    for k in names:
-        os.environ[k] = "0"
-    try:
-        yield
-    finally:
-        for k in names:
-            if old[k] is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = old[k]

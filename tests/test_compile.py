@@ -84,9 +84,7 @@ def test_bvh_leaf_order_and_node_visits_match_the_oracle(pkg, orc):
     ids = [b.sphere(rng.uniform(-8, 8, 3), rng.uniform(0.1, 1.0), m) for _ in range(137)]
     root = b.bvh(ids)
     desc = b.desc(root)
-    from conftest import reference_shaped_lists
-    with reference_shaped_lists():        # the reference's tree as it is: no extra boxes around spheres that share a node
-        nodes, spheres, meta = pkg.compile_dump(desc)
+    nodes, spheres, meta = pkg.compile_dump(desc, pkg._abi.RT_LAYOUT_REFERENCE_COUNTERS)   # the reference's tree as it is: no extra boxes around spheres that share a node
     out = (C.c_int32 * 256)()
     n = orc.lib().orc_bvh_leaf_order(C.byref(desc), root, out, 256)
     assert n == 137

@@ -19,7 +19,6 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import crops as K   # noqa: E402
-from conftest import reference_shaped_lists   # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -30,6 +29,9 @@ TOL = {
     # the book-2 frame is nearly black under the reference's DiffuseLight (front face only): mean radiance ~2e-3, so sqrt gamma turns
     # tiny linear differences into 8-bit steps; the r = 5000 fog sphere makes the scene extent (hence the box padding) large
     "C3": dict(mean=1.5e-4, bad=0.027, bit8=0.93, seg=5e-3, node=0.10, prim=0.27),     # measured 7.3e-5, 0.014, 0.965, 2.4e-3, 4.9e-2, 0.13
+    # the lit twins (tests/crops.py): FlipFace around the light, everything else as the literal scenes. PROVISIONAL until measured.
+    "C3lit": dict(mean=5e-3, bad=0.5, bit8=0.95, seg=5e-3, node=0.10, prim=0.27),
+    "SMOKElit": dict(mean=5e-3, bad=0.5, bit8=0.95, seg=5e-3, node=1e-9, prim=0.05),
     "C4": dict(mean=2.6e-4, bad=0.014, bit8=0.997, seg=2e-5, node=1e-9, prim=2e-5),    # measured 1.3e-4, 6.8e-3, 0.9987, 7e-6, 0 (no BVH), 8e-6
     # C5 walks 16-byte compressed records (corners on a u16 grid over the scene): boxes a grid step looser, so more tests — culling only
     "C5": dict(mean=4e-4, bad=0.025, bit8=0.99, seg=7e-4, node=0.05, prim=0.16),       # measured 2.0e-4, 0.012, 0.996, 3.4e-4, 2.4e-2, 8.1e-2
@@ -59,8 +61,7 @@ def check_config(pkg, gpu, name, tmp_path, earth, sah=False):
     W, H, spp = cfg["width"], cfg["height"], cfg["spp"]
     hs = K.host_scene(pkg, name, tmp_path, sah=sah, earth=earth)
     scene = gpu.upload(hs.desc)
-    with reference_shaped_lists():          # for the counters: list members as the reference walks them (conftest.py)
-        scene_counts = gpu.upload(hs.desc)
+    scene_counts = gpu.upload(hs.desc, A.RT_LAYOUT_REFERENCE_COUNTERS)          # for the counters: the layout the reference walks (include/rt_hip.h)
     cam = hs.camera(W / H)
     img, st = gpu.render(scene, cam, pkg.make_params(W, H, spp, max_depth=50, seed=cfg["seed"]))
     assert np.isfinite(img).all() and st["samples"] == W * H * spp
@@ -104,6 +105,17 @@ def test_c2_book1_1200x800x500(pkg, gpu, tmp_path):
 
 def test_c3_book2_final_800x800x1000(pkg, gpu, tmp_path, earth):
     check_config(pkg, gpu, "C3", tmp_path, earth)
+
+
+def test_c3_lit_twin_800x800x1000(pkg, gpu, tmp_path, earth):
+    """Config 3 with light in it: final_scene with its light wrapped in FlipFace (main.rs:359-361 does that for Cornell). The literal frame
+    above is nearly black under HEAD's DiffuseLight (material.rs:184-190), so THIS frame is where the earth image, the Perlin sphere, the
+    fog and the subsurface sphere are compared at values that carry signal."""
+    check_config(pkg, gpu, "C3lit", tmp_path, earth)
+
+
+def test_cornell_smoke_lit_twin_600x600x1000(pkg, gpu, tmp_path):
+    check_config(pkg, gpu, "SMOKElit", tmp_path, None)
 
 
 def test_c4_cornell_600x600x1000(pkg, gpu, tmp_path):

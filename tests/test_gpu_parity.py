@@ -43,12 +43,10 @@ def test_book1_same_seed_vs_f64_oracle(pkg, orc, gpu, book1):
     assert st["samples"] == ost["samples"] == W * H * SPP
     assert abs(st["segments"] - ost["segments"]) / ost["segments"] < 2e-3
     assert st["bvh_in_lds"] == 1
-    # the reference-shaped layout (conftest.reference_shaped_lists) walks the same tree in the same order as the CPU restatement: the same
+    # the reference-shaped layout (RT_LAYOUT_REFERENCE_COUNTERS, include/rt_hip.h) walks the same tree in the same order as the CPU restatement: the same
     # frame as the default layout bit for bit, and traversal work that agrees to a fraction of a percent (device boxes are inflated by
     # ~1e-6 * scene extent — they absorb the slab test's rounding — hence a few 0.1 % more visits)
-    from conftest import reference_shaped_lists
-    with reference_shaped_lists():
-        plain = gpu.upload(hs.desc)
+    plain = gpu.upload(hs.desc, pkg._abi.RT_LAYOUT_REFERENCE_COUNTERS)
     img_p, sp = gpu.render(plain, cam, prm)
     assert np.array_equal(img, img_p) and sp["segments"] == st["segments"]
     assert 0 <= (sp["node_tests"] - ost["node_tests"]) / ost["node_tests"] < 1e-2
@@ -235,32 +233,22 @@ def test_drain_kernel_is_bit_identical(pkg, gpu, earth):
     A = pkg._abi
     SB = A.RT_FLAG_SAMPLE_BLOCKS
     cases = [("book1", {}, 120, 80, 6), ("cornell", {}, 64, 64, 5), ("cornell_smoke", {}, 48, 48, 4), ("final", {"image": earth}, 56, 56, 3), ("book1_ref", {}, 64, 40, 4)]
-    old = os.environ.get("RT_DRAIN_AT")
-    try:
-        for name, kw, W, H, spp in cases:
-            hs = pkg.HostScene(name, 1, **kw)
-            scene = gpu.upload(hs.desc)
-            cam = hs.camera(W / H)
-            os.environ["RT_DRAIN_AT"] = "0"
-            ref, sr = gpu.render(scene, cam, pkg.make_params(W, H, spp, seed=3, flags=A.RT_FLAG_COUNTERS))
-            assert sr["drain_paths"] == 0
-            for drain_at, flags, pool in [("64", 0, 0), ("1000", 0, 0), ("100000000", 0, 0), ("0", A.RT_FLAG_FUSED, 0), ("0", A.RT_FLAG_FUSED, 256), ("300", 0, 512)]:
-                os.environ["RT_DRAIN_AT"] = drain_at
-                img, st = gpu.render(scene, cam, pkg.make_params(W, H, spp, seed=3, flags=flags | A.RT_FLAG_COUNTERS, pool_slots=pool))
-                # (a small threshold can be stepped over: the host learns the pool size a few iterations late, by design)
-                assert st["drain_paths"] > 0 or int(drain_at) < 1000, (name, drain_at, flags, pool)
-                assert np.array_equal(img, ref), (name, drain_at, flags, pool)
-                assert st["samples"] == sr["samples"] and st["segments"] == sr["segments"], (name, drain_at, flags, pool)
-                assert st["node_tests"] == sr["node_tests"] and st["prim_tests"] == sr["prim_tests"], (name, drain_at, flags, pool)
-            # multi-sample work items: the drain regenerates camera rays inside an item and carries its running sum
-            os.environ["RT_DRAIN_AT"] = "0"
-            a16, _ = gpu.render(scene, cam, pkg.make_params(W, H, 20, seed=3, flags=SB))
-            os.environ["RT_DRAIN_AT"] = "500"
-            b16, st = gpu.render(scene, cam, pkg.make_params(W, H, 20, seed=3, flags=SB))
-            c16, _ = gpu.render(scene, cam, pkg.make_params(W, H, 20, seed=3, flags=SB | A.RT_FLAG_FUSED, pool_slots=256))
-            assert np.array_equal(a16, b16) and np.array_equal(a16, c16), name
-    finally:
-        if old is None:
-            os.environ.pop("RT_DRAIN_AT", None)
-        else:
-            os.environ["RT_DRAIN_AT"] = old
+    NEVER = 1          # RtParams.tail_paths: 1 = the wavefront loop runs to the end
+    for name, kw, W, H, spp in cases:
+        hs = pkg.HostScene(name, 1, **kw)
+        scene = gpu.upload(hs.desc)
+        cam = hs.camera(W / H)
+        ref, sr = gpu.render(scene, cam, pkg.make_params(W, H, spp, seed=3, flags=A.RT_FLAG_COUNTERS, tail_paths=NEVER))
+        assert sr["drain_paths"] == 0
+        for tail, flags, pool in [(64, 0, 0), (1000, 0, 0), (100000000, 0, 0), (NEVER, A.RT_FLAG_FUSED, 0), (NEVER, A.RT_FLAG_FUSED, 256), (300, 0, 512)]:
+            img, st = gpu.render(scene, cam, pkg.make_params(W, H, spp, seed=3, flags=flags | A.RT_FLAG_COUNTERS, pool_slots=pool, tail_paths=tail))
+            # (a small threshold can be stepped over: the host learns the pool size a few iterations late, by design)
+            assert st["drain_paths"] > 0 or tail < 1000, (name, tail, flags, pool)
+            assert np.array_equal(img, ref), (name, tail, flags, pool)
+            assert st["samples"] == sr["samples"] and st["segments"] == sr["segments"], (name, tail, flags, pool)
+            assert st["node_tests"] == sr["node_tests"] and st["prim_tests"] == sr["prim_tests"], (name, tail, flags, pool)
+        # multi-sample work items: the drain regenerates camera rays inside an item and carries its running sum
+        a16, _ = gpu.render(scene, cam, pkg.make_params(W, H, 20, seed=3, flags=SB, tail_paths=NEVER))
+        b16, st = gpu.render(scene, cam, pkg.make_params(W, H, 20, seed=3, flags=SB, tail_paths=500))
+        c16, _ = gpu.render(scene, cam, pkg.make_params(W, H, 20, seed=3, flags=SB | A.RT_FLAG_FUSED, pool_slots=256, tail_paths=NEVER))
+        assert np.array_equal(a16, b16) and np.array_equal(a16, c16), name

@@ -54,15 +54,13 @@ def test_book1_reference_variant_moving_spheres_checker(pkg, orc, gpu):
 
 
 def test_book2_final_scene(pkg, orc, gpu, earth):
-    from conftest import reference_shaped_lists
     hs = pkg.HostScene("final", 1, image=earth)
     img, ref, st, ost = check(pkg, orc, gpu, hs.desc, hs.camera(1.0), 80, 80, 16)
     assert abs(st["prim_tests"][1] - st["segments"]) <= 8       # the one moving sphere is a list member: every segment probes it (when its walk begins)
     assert st["segments"] - 8 <= st["prim_tests"][4] < 1.9 * st["segments"]   # so does the fog; the other medium only where a ray meets its box
     # the list as the reference walks it: every member in front of every ray — the same picture, bit for bit, and the reference's counts
     prm = pkg.make_params(80, 80, 16, flags=pkg._abi.RT_FLAG_COUNTERS)
-    with reference_shaped_lists():
-        scene = gpu.upload(hs.desc)
+    scene = gpu.upload(hs.desc, pkg._abi.RT_LAYOUT_REFERENCE_COUNTERS)
     img_r, sr = gpu.render(scene, hs.camera(1.0), prm)
     assert np.array_equal(img, img_r) and sr["segments"] == st["segments"]
     assert abs(sr["prim_tests"][4] - 2 * sr["segments"]) <= 8 and abs(sr["prim_tests"][1] - sr["segments"]) <= 8
@@ -201,9 +199,7 @@ def test_config5_million_spheres_and_mesh(pkg, orc, gpu):
     assert (np.abs(img - img2).max(axis=2) > 0).mean() < 2e-3
     # one record array in the builder's child order against the default, one array per direction octant ordered near-first
     # (rt_api.cpp octant_order): the same picture up to such ties, with far fewer visits
-    from conftest import reference_shaped_lists
-    with reference_shaped_lists():
-        one_order = gpu.upload(hs.desc)
+    one_order = gpu.upload(hs.desc, pkg._abi.RT_LAYOUT_REFERENCE_COUNTERS)
     img3, st3 = gpu.render(one_order, cam, prm)
     assert (np.abs(img - img3).max(axis=2) > 0).mean() < 2e-3 and abs(st3["segments"] - st["segments"]) <= 1e-4 * st["segments"]
     assert st["node_tests"] < 0.85 * st3["node_tests"] and sum(st["prim_tests"][:5]) < 0.85 * sum(st3["prim_tests"][:5])
@@ -234,23 +230,14 @@ def test_time_survives_a_glass_bounce(pkg, orc, gpu):
         ids.append(b.moving_sphere(c, c + (0, rng.uniform(0.1, 0.5), 0), 0.0, 1.0, 0.3, lam) if i % 2 else b.sphere(c, 0.3, glass))
     desc = b.desc(b.bvh(ids, 0.0, 1.0))
     scene = gpu.upload(desc)
-    old = os.environ.get("RT_DRAIN_AT")
-    try:
-        for t1 in (0.0, 1.0):
-            cam = pkg.camera_new((5, 2, 2), (0, 0.3, 0), (0, 1, 0), 40, 1.5, 0.0, 10.0, 0.0, t1)
-            for depth in (2, 50):
-                os.environ["RT_DRAIN_AT"] = "0"
-                w, sw = gpu.render(scene, cam, pkg.make_params(96, 64, 8, seed=3, max_depth=depth, flags=A.RT_FLAG_COUNTERS))
-                f, sf = gpu.render(scene, cam, pkg.make_params(96, 64, 8, seed=3, max_depth=depth, flags=A.RT_FLAG_COUNTERS | A.RT_FLAG_FUSED))
-                assert np.array_equal(w, f) and sw["node_tests"] == sf["node_tests"] and sw["prim_tests"] == sf["prim_tests"], (t1, depth)
-        os.environ.pop("RT_DRAIN_AT", None)
-        cam = pkg.camera_new((5, 2, 2), (0, 0.3, 0), (0, 1, 0), 40, 1.5, 0.0, 10.0, 0.0, 1.0)
-        check(pkg, orc, gpu, desc, cam, 96, 64, 16)
-    finally:
-        if old is None:
-            os.environ.pop("RT_DRAIN_AT", None)
-        else:
-            os.environ["RT_DRAIN_AT"] = old
+    for t1 in (0.0, 1.0):
+        cam = pkg.camera_new((5, 2, 2), (0, 0.3, 0), (0, 1, 0), 40, 1.5, 0.0, 10.0, 0.0, t1)
+        for depth in (2, 50):
+            w, sw = gpu.render(scene, cam, pkg.make_params(96, 64, 8, seed=3, max_depth=depth, flags=A.RT_FLAG_COUNTERS, tail_paths=1))   # 1 = never hand over
+            f, sf = gpu.render(scene, cam, pkg.make_params(96, 64, 8, seed=3, max_depth=depth, flags=A.RT_FLAG_COUNTERS | A.RT_FLAG_FUSED))
+            assert np.array_equal(w, f) and sw["node_tests"] == sf["node_tests"] and sw["prim_tests"] == sf["prim_tests"], (t1, depth)
+    cam = pkg.camera_new((5, 2, 2), (0, 0.3, 0), (0, 1, 0), 40, 1.5, 0.0, 10.0, 0.0, 1.0)
+    check(pkg, orc, gpu, desc, cam, 96, 64, 16)
 
 
 def test_list_culling_and_prologue_change_nothing_but_the_counters(pkg, orc, gpu):
@@ -259,8 +246,6 @@ def test_list_culling_and_prologue_change_nothing_but_the_counters(pkg, orc, gpu
     a rotated box, an instanced box, loose rects, triangles and a nested list. The culled layout, the layout forced for every scene
     (RT_LIST_CULL=2) and the reference's layout (every member in front of every ray) render the same frame bit for bit; the oracle agrees
     within the usual tolerances; the culled walk makes fewer primitive tests."""
-    import os
-    from conftest import reference_shaped_lists
     rng = np.random.default_rng(11)
     b = pkg.SceneBuilder(background=(0.55, 0.65, 0.9))
     grey, red, glass, steel = b.lambertian((0.6, 0.6, 0.6)), b.lambertian((0.7, 0.2, 0.15)), b.dielectric(1.5), b.metal((0.8, 0.8, 0.9), 0.05)
@@ -284,14 +269,9 @@ def test_list_culling_and_prologue_change_nothing_but_the_counters(pkg, orc, gpu
     W, H, SPP = 150, 100, 16
     img, ref, st, ost = check(pkg, orc, gpu, desc, cam, W, H, SPP, bad_tol=0.03, seg_tol=3e-3)
     prm = pkg.make_params(W, H, SPP, flags=pkg._abi.RT_FLAG_COUNTERS)
-    with reference_shaped_lists():
-        plain = gpu.upload(desc)
+    plain = gpu.upload(desc, pkg._abi.RT_LAYOUT_REFERENCE_COUNTERS)
     img_p, sp = gpu.render(plain, cam, prm)
-    os.environ["RT_LIST_CULL"] = "2"
-    try:
-        forced = gpu.upload(desc)
-    finally:
-        os.environ.pop("RT_LIST_CULL", None)
+    forced = gpu.upload(desc, pkg._abi.RT_LAYOUT_LISTS_CULLED)
     img_f, sf = gpu.render(forced, cam, prm)
     assert np.array_equal(img, img_p) and np.array_equal(img, img_f)
     assert st["segments"] == sp["segments"] == sf["segments"] and st["prim_tests"] == sf["prim_tests"]
@@ -305,8 +285,6 @@ def test_random_graphs_render_the_same_under_every_layout(pkg, gpu, seed):
     """Random object graphs — lists in lists, BVHs in lists, instanced boxes and spheres, media with sphere and box boundaries, moving and
     hollow spheres, loose rects and triangles, in random order — rendered under the layouts the uploader can choose: list members culled
     and every-ray members in the prologue (forced), pair members boxed (forced), versus the reference's shape. Same frame, bit for bit."""
-    import os
-    from conftest import reference_shaped_lists
     rng = np.random.default_rng(100 + seed)
     b = pkg.SceneBuilder(background=(0.6, 0.7, 0.95))
     mats = [b.lambertian(tuple(rng.uniform(0.2, 0.8, 3))) for _ in range(4)] + [b.metal((0.8, 0.8, 0.8), float(rng.uniform(0, 0.3))), b.dielectric(1.5)]
@@ -343,15 +321,10 @@ def test_random_graphs_render_the_same_under_every_layout(pkg, gpu, seed):
     desc = b.desc(b.hittable_list([top[i] for i in order]))
     cam = pkg.camera_new((0, 3, 14), (0, 0.8, 0), (0, 1, 0), 40, 1.5, 0.05, 14.0, 0, 1)
     prm = pkg.make_params(96, 64, 4, seed=seed, flags=pkg._abi.RT_FLAG_COUNTERS)
-    with reference_shaped_lists():
-        plain = gpu.upload(desc)
+    plain = gpu.upload(desc, pkg._abi.RT_LAYOUT_REFERENCE_COUNTERS)
     ref, sr = gpu.render(plain, cam, prm)
     assert np.isfinite(ref).all() and sr["segments"] > 96 * 64 * 4
-    os.environ["RT_LIST_CULL"] = "2"; os.environ["RT_PAIR_BOXES"] = "2"
-    try:
-        forced = gpu.upload(desc)
-    finally:
-        os.environ.pop("RT_LIST_CULL", None); os.environ.pop("RT_PAIR_BOXES", None)
+    forced = gpu.upload(desc, pkg._abi.RT_LAYOUT_LISTS_CULLED | pkg._abi.RT_LAYOUT_MEMBER_BOXES)
     img, st = gpu.render(forced, cam, prm)
     assert np.array_equal(img, ref) and st["segments"] == sr["segments"], seed
     img_d, sd = gpu.render(gpu.upload(desc), cam, prm)          # what the uploader picks by itself
