@@ -41,9 +41,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("RT_ORACLE_LIB", LIB_PATH)     # a sanitizer build of the checker (scripts/asan_host.sh)
+        if path == LIB_PATH and not os.path.exists(LIB_PATH):
             build()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         vp, f64p = C.c_void_p, C.POINTER(C.c_double)
         L.orc_last_error.restype = C.c_char_p
         L.orc_render.restype = C.c_int

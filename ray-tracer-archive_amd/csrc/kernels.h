@@ -108,6 +108,8 @@ struct LaunchCfg {
     uint32_t max_rays;        // upper bound of the rays in the queue of this launch of k_extend (sizes its grid when the queue is short)
 };
 
+// what a launcher has to say about the error it has just returned (nullptr: nothing beyond hipGetErrorString)
+const char* launch_note();
 hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_init, uint32_t* next_work, uint32_t* out_count, hipStream_t stream);
 // One wavefront iteration = launch_extend then launch_shade. No memsets in between: k_extend zeroes
 // the count the following k_shade appends to, k_shade zeroes the queue head of the next k_extend.

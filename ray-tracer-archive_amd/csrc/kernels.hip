@@ -1662,6 +1662,22 @@ __global__ void __launch_bounds__(256) k_untile(const T* __restrict__ gathered, 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+static thread_local const char* g_launch_note = nullptr;
+const char* launch_note() { return g_launch_note; }
+// k_extend addresses its staged scene by LDS ADDRESS: a record's address in the threaded array IS its LDS address, which holds only while
+// the kernel has no static LDS (the dynamic segment then starts at 0). A __shared__ variable or a builtin with LDS scratch
+// (__syncthreads_or was one: commit 65ed0b5, found as a hang) would shift the staged copy and send every walk through garbage links.
+// Checked once per instantiation against the code object that was actually loaded; a violation is an error, not a hang.
+template <class K> static hipError_t check_no_static_lds(K kernel) {
+    hipFuncAttributes fa{};
+    const hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel));
+    if (e != hipSuccess) return e;
+    if (fa.sharedSizeBytes != 0) {
+        g_launch_note = "k_extend was built with static LDS: its staged scene no longer starts at LDS address 0 (kernels.hip check_no_static_lds)";
+        return hipErrorInvalidDeviceFunction;
+    }
+    return hipSuccess;
+}
 // Persistent grid of k_extend = what is resident at once. Registers and the LDS copy of the scene both
 // limit it; a scene whose LDS copy is large (book-2 final: 65 KB; the 64 KB top of a tree that does not fit) allows two workgroups
 // per CU, and then larger workgroups keep more waves. The runtime's occupancy query decides between the sizes compiled per mode.
@@ -1677,6 +1693,8 @@ static hipError_t launch_drain_c(const SceneDev& sc, const PoolDev& pool, const 
                                  uint32_t* next_work, unsigned long long* counters, hipStream_t stream) {
     const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u + sc.ext_blob_bytes) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
     constexpr uint32_t T = kExtendThreads;
+    static thread_local bool checked = false;
+    if (!checked) { const hipError_t e = check_no_static_lds(k_extend<MODE, FEAT, COUNT, T, true>); if (e != hipSuccess) return e; checked = true; }
     // max_count = upper bound of the paths in ONE queue
     hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, T, true>), dim3(kQueues * ((max_count + T - 1u) / T)), dim3(T), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd, next_work);
     return hipGetLastError();
@@ -1694,7 +1712,12 @@ static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, cons
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[0], k_extend<MODE, FEAT, COUNT, T0, false>, (int)T0, lds_bytes);
         if (e != hipSuccess) return e;
         nb[1] = nb[2] = 0;
+        e = check_no_static_lds(k_extend<MODE, FEAT, COUNT, T0, false>);
+        if (e != hipSuccess) return e;
         if (!kNoLds) {
+            e = check_no_static_lds(k_extend<MODE, FEAT, COUNT, T1, false>);
+            if (e == hipSuccess) e = check_no_static_lds(k_extend<MODE, FEAT, COUNT, T2, false>);
+            if (e != hipSuccess) return e;
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[1], k_extend<MODE, FEAT, COUNT, T1, false>, (int)T1, lds_bytes);
             if (e != hipSuccess) return e;
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[2], k_extend<MODE, FEAT, COUNT, T2, false>, (int)T2, lds_bytes);

@@ -34,7 +34,17 @@ template <class T> int upload(RtCtx* ctx, DevBuf& b, const std::vector<T>& v) {
 
 }  // namespace
 
-static uint32_t scene_features(const rtc::CompiledScene& cs);
+static uint32_t scene_features(const rtc::CompiledScene& cs) {
+    uint32_t f = 0;
+    if (!cs.moving_meta.empty()) f |= rtk::F_MOVING;
+    if (!cs.rect_meta.empty()) f |= rtk::F_RECT;
+    if (!cs.tri_meta.empty()) f |= rtk::F_TRI;
+    if (!cs.media.empty()) f |= rtk::F_MEDIUM;
+    if (cs.xforms.size() > 1 || cs.wraps.size() > 1) f |= rtk::F_XFORM;
+    for (uint32_t mb : cs.mat_b) { const uint32_t kind = mb & 15u; if ((mb >> 4) != rtd::TEX_INLINE && kind != rtd::MK_METAL && kind != rtd::MK_DIELECTRIC) f |= rtk::F_TEX; }
+    if (cs.has_lights) f |= rtk::F_LIGHTS;
+    return f;
+}
 
 int rti::validate_params(RtCtx* ctx, const RtParams* p) {
     if (!p) return set_err(ctx, RT_ERR_INVALID, "params is null");
@@ -96,8 +106,7 @@ static int ctx_init(RtCtx* ctx, void* stream) {
     return RT_OK;
 }
 
-extern "C" {
-
+// (every rt_* entry point below is declared extern "C" by include/rt_hip.h; the definitions take their linkage from there)
 uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
 const char* rt_last_error(const RtCtx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
@@ -334,8 +343,6 @@ static size_t lds_scene_bytes(const rtc::CompiledScene& cs) {
     return (cs.nodes.size() + 2 + twins) * 32 + cs.spheres.size() * 16;
 }
 
-}  // extern "C"
-
 // ---- layout options: RtUploadOptions of the ABI, resolved once per upload ---------------------------------------------------------------
 // Environment variables are OVERRIDES for the experiment scripts under scripts/ only (they predate the ABI fields and keep the A/B
 // scripts one-liners); no test and no host path sets them. A process that never sets them gets exactly what its RtUploadOptions say.
@@ -531,8 +538,6 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     return RT_OK;
 }
 
-extern "C" {
-
 int rt_scene_upload_ex(RtCtx* ctx, const RtSceneDesc* desc, const RtUploadOptions* options, RtScene** out_scene) {
     if (!ctx) return set_err(nullptr, RT_ERR_INVALID, "ctx is null");
     if (!desc || !out_scene) return set_err(ctx, RT_ERR_INVALID, "desc / out_scene is null");
@@ -564,6 +569,13 @@ int rt_output_floats(const RtParams* p, uint64_t* out_n) {
     else *out_n = (uint64_t)t.n_local * t.ts * t.ts * 3u;
     return RT_OK;
 }
+
+// a launcher's own explanation (kernels.h launch_note) in front of the HIP error string
+#define LAUNCH_TRY(call)                                                                                                        \
+    do {                                                                                                                        \
+        hipError_t e_ = (call);                                                                                                 \
+        if (e_ != hipSuccess) return set_err(ctx, RT_ERR_DEVICE, std::string(rtk::launch_note() ? rtk::launch_note() : #call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
 
 static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtParams* prm, void* d_out, RtStats* stats) {
     using clk = std::chrono::steady_clock;
@@ -722,7 +734,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         if ((uint64_t)live * rtk::kQueues <= drain_at) {
             hipEvent_t ea = nullptr, eb = nullptr;
             if (timing) HIP_TRY(ctx, next_event(ea));
-            HIP_TRY(ctx, rtk::launch_drain(cfg, scene->dev, pd[cur], rd, live, c_count[cur], c_head, c_count[1 - cur], c_next_work, c64, counting, ctx->stream));
+            LAUNCH_TRY(rtk::launch_drain(cfg, scene->dev, pd[cur], rd, live, c_count[cur], c_head, c_count[1 - cur], c_next_work, c64, counting, ctx->stream));
             if (timing) { HIP_TRY(ctx, next_event(eb)); spans.push_back({ea, eb, 3}); }
             drained = live * rtk::kQueues;
             break;
@@ -730,7 +742,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
         if (timing) HIP_TRY(ctx, next_event(ea));
         cfg.max_rays = (uint32_t)std::min<uint64_t>((uint64_t)live * rtk::kQueues, 0xFFFFFFFFull);
-        HIP_TRY(ctx, rtk::launch_extend(cfg, scene->dev, pd[cur], rd, c_count[cur], c_head, c_count[1 - cur], c64, counting, ctx->stream));
+        LAUNCH_TRY(rtk::launch_extend(cfg, scene->dev, pd[cur], rd, c_count[cur], c_head, c_count[1 - cur], c64, counting, ctx->stream));
         if (timing) HIP_TRY(ctx, next_event(eb));
         HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, c_count[cur], c_count[1 - cur], c_next_work, c_head, c64, counting,
                                        ctx->stream));
@@ -812,18 +824,6 @@ int rt_render(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, const RtPar
 
 int rt_untile(const RtParams* p, const float* gathered, float* rgb_sum) { return untile_host<float>(p, gathered, rgb_sum); }
 int rt_untile_rgb8(const RtParams* p, const uint8_t* gathered, uint8_t* rgb8) { return untile_host<uint8_t>(p, gathered, rgb8); }
-
-static uint32_t scene_features(const rtc::CompiledScene& cs) {
-    uint32_t f = 0;
-    if (!cs.moving_meta.empty()) f |= rtk::F_MOVING;
-    if (!cs.rect_meta.empty()) f |= rtk::F_RECT;
-    if (!cs.tri_meta.empty()) f |= rtk::F_TRI;
-    if (!cs.media.empty()) f |= rtk::F_MEDIUM;
-    if (cs.xforms.size() > 1 || cs.wraps.size() > 1) f |= rtk::F_XFORM;
-    for (uint32_t mb : cs.mat_b) { const uint32_t kind = mb & 15u; if ((mb >> 4) != rtd::TEX_INLINE && kind != rtd::MK_METAL && kind != rtd::MK_DIELECTRIC) f |= rtk::F_TEX; }
-    if (cs.has_lights) f |= rtk::F_LIGHTS;
-    return f;
-}
 
 int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out) { return rt_scene_compile_info_ex(desc, nullptr, out); }
 int rt_scene_compile_info_ex(const RtSceneDesc* desc, const RtUploadOptions* options, RtCompileInfo* out) {
@@ -913,4 +913,3 @@ int rt_resolve_device(RtCtx* ctx, const void* rgb_sum_device, uint32_t width, ui
     return RT_OK;
 }
 
-}  // extern "C"

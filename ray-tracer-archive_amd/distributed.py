@@ -53,12 +53,40 @@ def render_gathered(ctx, scene, cam, base, rank, output_kind=A.RT_OUT_RGB_SUM_F3
     return frame, st
 
 
-def init_comm_guarded(ctx, rank, world, dist, timeout_s=180.0):
+class CollectiveTimeout(RuntimeError):
+    """A rank did not come back from an RCCL call within its deadline: the process still holds a wedged GPU stream and a helper thread
+    inside the library, so nothing more can run in it."""
+
+
+def _die_on_timeout(reason, code=3):
+    """Default reaction to a timeout inside a guarded collective: say why and END THE PROCESS, non-zero. A hung ncclRecv sits on the
+    context's stream (every later launch on it would queue behind it for ever) and the helper thread is still inside the library on a
+    context that is not thread-safe: a fresh process is the only safe retry (the launcher's job). A REFUSAL — the helper came back with an
+    error — is different: nothing is in flight, and the caller may fall back to render_gathered_staged in the same process."""
+    import os
+    import sys
+    print("FATAL: " + reason + " — ending this process (a hung collective cannot be recovered from in-process)", file=sys.stderr, flush=True)
+    os._exit(code)
+
+
+def _agree(dist, world, mine, timed_out, on_timeout):
+    """Every rank learns every rank's outcome (`mine` = '' or a reason; `timed_out` = this rank's helper thread is still running).
+    Returns (ok, reasons joined). If ANY rank timed out, every rank ends through `on_timeout` (default: _die_on_timeout)."""
+    outcomes = [None] * world
+    dist.all_gather_object(outcomes, (mine, bool(timed_out)))
+    ok = all(not m for m, _ in outcomes)
+    why = "" if ok else "; ".join(f"rank {r}: {m}" for r, (m, _) in enumerate(outcomes) if m)
+    if any(t for _, t in outcomes):
+        on_timeout(why)
+        raise CollectiveTimeout(why)          # only reached when a test's on_timeout returns
+    return ok, why
+
+
+def init_comm_guarded(ctx, rank, world, dist, timeout_s=180.0, on_timeout=_die_on_timeout):
     """init_comm + rt_comm_selftest on a helper thread with a deadline; every rank learns whether ALL ranks got their communicator.
-    Returns (ok, reason). A launcher uses it to fall back to render_gathered_staged instead of dying on a node whose RCCL set-up fails
-    (a hung set-up leaves the helper thread behind; the process still ends through the launcher)."""
+    Returns (ok, reason) when every rank came back: ok False = RCCL REFUSED somewhere (nothing in flight; a launcher may fall back to
+    render_gathered_staged). A rank that did NOT come back within the deadline ends every rank's process (see _die_on_timeout)."""
     import threading
-    import torch
     err = []
 
     def work():
@@ -70,21 +98,17 @@ def init_comm_guarded(ctx, rank, world, dist, timeout_s=180.0):
     t = threading.Thread(target=work, daemon=True)
     t.start()
     t.join(timeout_s)
-    mine = "" if (not t.is_alive() and not err) else (err[0] if err else f"RCCL set-up did not finish within {timeout_s:.0f} s")
-    flag = torch.tensor([0.0 if mine else 1.0], dtype=torch.float64)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    reasons = [None] * world
-    dist.all_gather_object(reasons, mine)
-    ok = bool(flag.item() == 1.0)
-    return ok, "" if ok else "; ".join(f"rank {r}: {m}" for r, m in enumerate(reasons) if m)
+    timed_out = t.is_alive()
+    mine = f"RCCL set-up did not finish within {timeout_s:.0f} s" if timed_out else (err[0] if err else "")
+    return _agree(dist, world, mine, timed_out, on_timeout)
 
 
-def trial_gather(ctx, scene, cam, rank, world, dist, device, width=160, height=96, spp=2, timeout_s=120.0):
+def trial_gather(ctx, scene, cam, rank, world, dist, device, width=160, height=96, spp=2, timeout_s=120.0, on_timeout=_die_on_timeout):
     """One small rt_render_gather through the freshly made communicator, on a helper thread with a deadline; rank 0 renders the same
     frame alone and compares bit for bit (the picture does not depend on the number of shards). Every rank learns the outcome. This is
-    the first time the exchange runs between the devices of THIS node, so a launcher calls it before it trusts rt_render_gather."""
+    the first time the exchange runs between the devices of THIS node, so a launcher calls it before it trusts rt_render_gather.
+    (ok, reason) as init_comm_guarded: a refusal or a wrong frame comes back as ok False, a timeout ends the processes."""
     import threading
-    import torch
     base = api.make_params(width, height, spp, max_depth=50, seed=1)
     box = {}
 
@@ -97,8 +121,8 @@ def trial_gather(ctx, scene, cam, rank, world, dist, device, width=160, height=9
     t = threading.Thread(target=work, daemon=True)
     t.start()
     t.join(timeout_s)
-    mine = ""
-    if t.is_alive():
+    mine, timed_out = "", t.is_alive()
+    if timed_out:
         mine = f"rt_render_gather did not return within {timeout_s:.0f} s"
     elif "err" in box:
         mine = box["err"]
@@ -106,30 +130,41 @@ def trial_gather(ctx, scene, cam, rank, world, dist, device, width=160, height=9
         own, _ = ctx.render(scene, cam, base)
         if not np.array_equal(box["frame"].cpu().numpy(), own):
             mine = "gathered frame differs from rank 0's own render of the same frame"
-    flag = torch.tensor([0.0 if mine else 1.0], dtype=torch.float64)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    reasons = [None] * world
-    dist.all_gather_object(reasons, mine)
-    ok = bool(flag.item() == 1.0)
-    return ok, "" if ok else "; ".join(f"rank {r}: {m}" for r, m in enumerate(reasons) if m)
+    return _agree(dist, world, mine, timed_out, on_timeout)
 
 
 def render_gathered_staged(ctx, scene, cam, base, rank, world, dist, output_kind=A.RT_OUT_RGB_SUM_F32, device=None, tile_size=32):
     """The same frame as render_gathered without RCCL: every rank renders its shard (rt_render_device), the shards travel through host
     memory over `dist` (gloo), rank 0 puts the tiles in place on its device (rt_untile_device). RGB8: write_color per shard first
     (rt_resolve_device on the shard buffer — it is per pixel, so tile order does not matter). Slow path for nodes where the library's
-    own exchange cannot be set up."""
+    own exchange cannot be set up.
+
+    Like rt_render_gather, the ranks AGREE before anything is gathered: a rank whose render failed still takes part, and every rank
+    raises — the failed one its own error, the others RtError(RT_ERR_PEER) naming it — instead of rank 0 waiting in the gather."""
     import torch
     prm = shard_params(base, rank, world, tile_size)
     n = shard_floats(base, world, tile_size)
-    out = torch.zeros(n, dtype=torch.float32, device=device)
-    torch.cuda.current_stream(out.device).synchronize()
-    st = ctx.render_device(scene, cam, prm, out.data_ptr())
-    if output_kind == A.RT_OUT_RGB8:
-        out8 = torch.empty(n, dtype=torch.uint8, device=device)
-        torch.cuda.current_stream(out.device).synchronize()
-        ctx.resolve_device(out.data_ptr(), n // 3, 1, base.samples_per_pixel, out8.data_ptr())
-        out = out8
+    mine, st, out = None, None, None
+    try:
+        out = torch.zeros(n, dtype=torch.float32, device=device)
+        if out.is_cuda:
+            torch.cuda.current_stream(out.device).synchronize()
+        st = ctx.render_device(scene, cam, prm, out.data_ptr())
+        if output_kind == A.RT_OUT_RGB8:
+            out8 = torch.empty(n, dtype=torch.uint8, device=device)
+            if out.is_cuda:
+                torch.cuda.current_stream(out.device).synchronize()
+            ctx.resolve_device(out.data_ptr(), n // 3, 1, base.samples_per_pixel, out8.data_ptr())
+            out = out8
+    except Exception as e:      # noqa: BLE001 — agreed on below, then re-raised
+        mine = e
+    outcomes = [None] * world
+    dist.all_gather_object(outcomes, None if mine is None else repr(mine))
+    failed = [r for r, m in enumerate(outcomes) if m is not None]
+    if failed:
+        if mine is not None:
+            raise mine
+        raise api.RtError(A.RT_ERR_PEER, f"rank {failed[0]} failed its part of the render ({outcomes[failed[0]]}): the gather was called off on every rank")
     host = out.cpu()
     parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
     dist.gather(host, gather_list=parts, dst=0)
@@ -137,7 +172,8 @@ def render_gathered_staged(ctx, scene, cam, base, rank, world, dist, output_kind
         return None, st
     gathered = torch.cat(parts).to(device)
     frame = torch.empty((base.height, base.width, 3), dtype=out.dtype, device=device)
-    torch.cuda.current_stream(frame.device).synchronize()
+    if frame.is_cuda:
+        torch.cuda.current_stream(frame.device).synchronize()
     ctx.untile_device(shard_params(base, 0, world, tile_size), output_kind, gathered.data_ptr(), frame.data_ptr())
     return frame, st
 

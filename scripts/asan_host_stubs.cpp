@@ -1,0 +1,15 @@
+// Stand-ins for the kernel launchers (csrc/kernels.hip) in the HOST-ONLY AddressSanitizer build of the library (scripts/asan_host.sh): that
+// build exists to run the host code — scene compiler, host mirror, tiling helpers, option handling — under ASan/UBSan on a box without
+// a GPU, where no entry point ever reaches a launch (rt_ctx_create returns RT_ERR_NO_DEVICE first). Never part of the product.
+#include "../ray-tracer-archive_amd/csrc/kernels.h"
+namespace rtk {
+const char* launch_note() { return "asan host build: no kernels"; }
+hipError_t launch_generate(const PoolDev&, const RenderDev&, uint32_t, uint32_t*, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_extend(const LaunchCfg&, const SceneDev&, const PoolDev&, const RenderDev&, const uint32_t*, uint32_t*, uint32_t*, unsigned long long*, bool, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_drain(const LaunchCfg&, const SceneDev&, const PoolDev&, const RenderDev&, uint32_t, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, unsigned long long*, bool, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_shade(const LaunchCfg&, const SceneDev&, const PoolDev&, const PoolDev&, const RenderDev&, uint32_t, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, unsigned long long*, bool, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_resolve(const RenderDev&, float*, uint32_t, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_write_color(const float*, uint32_t, uint32_t, uint8_t*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_untile_f32(const float*, float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_untile_u8(const uint8_t*, uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t, hipStream_t) { return hipErrorNotSupported; }
+}  // namespace rtk

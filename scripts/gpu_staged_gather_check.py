@@ -31,5 +31,22 @@ if rank == 0:
     same32 = bool(np.array_equal(f32.cpu().numpy(), ref)); same8 = bool(np.array_equal(u8.cpu().numpy(), ref8))
     print("world", world, "library exchange set up:", ok, "|", why[:120], "| staged f32 == single-GPU:", same32, "| staged RGB8 == write_color(single-GPU):", same8, flush=True)
     assert same32 and same8
+# a failure injected into rank 1's render (rt_test_fail_next_renders): every rank must come back with an error — rank 1 its own, the
+# others RT_ERR_PEER naming rank 1 — instead of rank 0 waiting in the gather; and the next frame must be fine again
+if world > 1:
+    if rank == 1:
+        ctx.fail_next_renders(1)
+    try:
+        D.render_gathered_staged(ctx, scene, cam, prm, rank, world, dist, A.RT_OUT_RGB_SUM_F32, device=dev)
+        outcome = "no error"
+    except pkg.RtError as e:
+        outcome = "own" if e.code == A.RT_ERR_DEVICE and "injected" in str(e) else ("peer1" if e.code == A.RT_ERR_PEER and "rank 1" in str(e) else repr(e))
+    got = [None] * world
+    dist.all_gather_object(got, outcome)
+    again, _ = D.render_gathered_staged(ctx, scene, cam, prm, rank, world, dist, A.RT_OUT_RGB_SUM_F32, device=dev)
+    if rank == 0:
+        fine = got[1] == "own" and all(g == "peer1" for r, g in enumerate(got) if r != 1) and bool(np.array_equal(again.cpu().numpy(), ref))
+        print("injected failure on rank 1:", got, "| every rank returned and the next frame is right:", fine, flush=True)
+        assert fine
 dist.barrier()
 dist.destroy_process_group()

@@ -31,7 +31,17 @@ def oracle_crops(pkg, name, tmp_dir, n_threads, earth=None, only=None):
     prm = pkg.make_params(cfg["width"], cfg["height"], cfg["spp"], max_depth=50, seed=cfg["seed"])
     names = [n for n in cfg["crops"] if only is None or n in only]
     imgs, stats = orc.render_crops(hs.desc, cam, prm, [cfg["crops"][n] for n in names], precision=64, n_threads=n_threads, count=True)
-    return names, imgs, stats
+    # per-pixel standard error of the mean (per channel), from the oracle's own per-sample radiances: the scale SURVEY 8(d)'s converged-mean
+    # test measures a difference against (|d| <= 4 SE). Needs enough samples per pixel to mean anything: skipped below 64 spp (config 5).
+    ses = []
+    for n in names:
+        if cfg["spp"] < 64:
+            ses.append(None)
+            continue
+        _, _, ps = orc.render(hs.desc, cam, prm, precision=64, n_threads=n_threads, rect=cfg["crops"][n], per_sample=True)
+        ses.append((ps.std(axis=2, ddof=1) / np.sqrt(cfg["spp"])).astype(np.float32))
+        del ps
+    return names, imgs, stats, ses
 
 
 def main():
@@ -47,11 +57,13 @@ def main():
                 from PIL import Image
                 earth = np.asarray(Image.open(os.path.join(K.GOLDEN, "earthmap_rgb.png")).convert("RGB"))
             t0 = time.time()
-            names, imgs, stats = oracle_crops(pkg, name, tmp, nt, earth)
+            names, imgs, stats, ses = oracle_crops(pkg, name, tmp, nt, earth)
             out = {}
-            for n, img, st in zip(names, imgs, stats):
+            for n, img, st, se in zip(names, imgs, stats, ses):
                 out[n] = img
                 out[n + "__counters"] = np.array([st["samples"], st["segments"], st["node_tests"]] + st["prim_tests"], dtype=np.uint64)
+                if se is not None:
+                    out[n + "__se"] = se
             np.savez_compressed(K.golden_path(name), **out)
             print(f"{name}: {len(names)} crops, {sum(s['samples'] for s in stats)} samples, {time.time() - t0:.1f} s ->", K.golden_path(name),
                   os.path.getsize(K.golden_path(name)) // 1024, "KiB")

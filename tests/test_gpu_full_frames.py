@@ -48,11 +48,20 @@ def record(**kw):
         pass
 
 
-def crop_metrics(pkg, a, ref, spp):
+def crop_metrics(pkg, a, ref, spp, se=None):
     d = np.abs(a.astype(np.float64) - ref) / spp
     a8, b8 = pkg.tonemap(np.ascontiguousarray(a), spp).astype(int), pkg.tonemap(np.ascontiguousarray(ref.astype(np.float32)), spp).astype(int)
-    return dict(mean=float(d.mean()), bad=float((d.max(axis=2) > 2e-3).mean()), bit8=float(np.mean(np.abs(a8 - b8) <= 2)),
-                rel_mean=float(abs(a.mean() - ref.mean()) / max(ref.mean(), 1e-30)))
+    m = dict(mean=float(d.mean()), bad=float((d.max(axis=2) > 2e-3).mean()), bit8=float(np.mean(np.abs(a8 - b8) <= 2)),
+             rel_mean=float(abs(a.mean() - ref.mean()) / max(ref.mean(), 1e-30)))
+    if se is not None:
+        # SURVEY 8(d)'s converged-mean test: |difference of the per-pixel means| against the pixel's standard error (the oracle's own
+        # per-sample spread / sqrt(spp), in the fixture). z = |d| / SE: an independent re-render would sit at ~1.1 on average; the same
+        # paths followed in f32 must sit far below it. se4 = share of pixel channels beyond 4 SE.
+        z = d / np.maximum(se.astype(np.float64), 1e-9)
+        lit = se > 1e-9                 # a channel no sample ever lit has SE 0: there the values must agree outright
+        m["zmean"] = float(z[lit].mean()) if lit.any() else 0.0
+        m["se4"] = float((z[lit] > 4.0).mean()) if lit.any() else 0.0
+    return m
 
 
 def check_config(pkg, gpu, name, tmp_path, earth, sah=False):
@@ -69,7 +78,7 @@ def check_config(pkg, gpu, name, tmp_path, earth, sah=False):
     results = []
     for crop, (x0, y0, x1, y1) in cfg["crops"].items():
         a, ref, ctr = img[y0:y1, x0:x1], g[crop], [int(v) for v in g[crop + "__counters"]]
-        m = crop_metrics(pkg, a, ref, spp)
+        m = crop_metrics(pkg, a, ref, spp, g.get(crop + "__se"))
         # the same tile as a one-tile shard, with the device counters on
         ti, n_tiles = K.tile_index(name, crop)
         buf, ts = gpu.render(scene_counts, cam, pkg.make_params(W, H, spp, max_depth=50, seed=cfg["seed"], flags=A.RT_FLAG_COUNTERS, tile_size=K.TILE,
@@ -92,6 +101,8 @@ def check_config(pkg, gpu, name, tmp_path, earth, sah=False):
         results.append((crop, m))
     for crop, m in results:          # every crop is measured (and recorded) before the first assert
         assert m["mean"] <= tol["mean"] and m["bad"] <= tol["bad"] and m["bit8"] >= tol["bit8"], (name, crop, m)
+        if "zmean" in m:
+            assert m["zmean"] <= tol.get("zmean", 0.25) and m["se4"] <= tol.get("se4", 2e-3) and m["rel_mean"] <= 5e-3, (name, crop, m)
         assert m["seg"] <= tol["seg"], (name, crop, m)
         if not sah:
             # same tree, same order: the device's boxes are a hair looser (they absorb the slab test's rounding), never tighter

@@ -116,3 +116,5 @@ def test_two_ranks_on_one_gpu_fall_back_to_the_staged_gather():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("world 2")]
     assert line and "staged f32 == single-GPU: True" in line[0] and "staged RGB8 == write_color(single-GPU): True" in line[0], r.stdout[-2000:]
+    # ... and a render failure injected into rank 1 comes back as an error on EVERY rank (its own on rank 1, RT_ERR_PEER on rank 0), no hang
+    assert "every rank returned and the next frame is right: True" in r.stdout, r.stdout[-2000:]
