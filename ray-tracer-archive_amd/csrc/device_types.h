@@ -27,9 +27,11 @@ enum LeafType : uint32_t {
     LT_RECT = 3,     // rects[]
     LT_TRI = 4,      // tris[]
     LT_MEDIUM = 5,   // media[]
-    LT_ENTER = 6,    // first = xform id: current ray := xform(world ray)      (Translate/RotateY::hit)
-    LT_EXIT = 7      // first = xform id to restore (0 = world ray)
+    LT_XFORM = 6,    // Translate/RotateY::hit: first & 0xFFFF = xform id the ray moves to (0 = the world ray); XFORM_EXIT set on the record that
+                     // closes a wrapper (restores the enclosing space), clear on the one that opens it
+    LT_BOX = 7       // boxes[]: a Box (boxes.rs:11-75) as ONE 32-byte record; its six sides stay in rects[] for shading, the hit id is the side's rect id
 };
+constexpr uint32_t XFORM_EXIT = 1u << 23;
 constexpr uint32_t LEAF_MAX_COUNT = 15;
 constexpr uint32_t MAX_PROLOGUE = 4;   // leaf payloads tested at the start of every walk instead of being met by it
 constexpr uint32_t LEAF_MAX_FIRST = (1u << 24) - 1;
@@ -82,6 +84,8 @@ struct Float4 { float x, y, z, w; };
 // moving   : 3 x Float4  (center0.xyz, radius) (center1.xyz, time0) (time1,0,0,0)  moving_sphere.rs:8-15
 // rect     : 2 x Float4  (a0, a1, b0, b1) (k, kaxis as float 0/1/2, 0, 0)        aarect.rs:10-17 (kaxis 2=Xy,1=Xz,0=Yz)
 // triangle : 3 x Float4  (v0,0) (v1,0) (v2,0)
+// box      : 2 x Float4  (x0, x1, y0, y1) (z0, z1, first side's rect index as u32 bits, 0): the six sides in boxes.rs order are rects
+//            first .. first+5 (z1 z0 y1 y0 x1 x0); k_extend tests them from this record in straight-line code (kernels.hip box_sides_hit)
 
 // hit record prim id: (leaf type << 28) | index into that type's array; 0 = miss
 constexpr uint32_t HIT_NONE = 0;

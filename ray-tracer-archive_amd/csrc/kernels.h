@@ -31,6 +31,7 @@ struct SceneDev {
     const rtd::Float4* moving; const uint32_t* moving_meta;
     const rtd::Float4* rects; const uint32_t* rect_meta;
     const rtd::Float4* tris; const uint32_t* tri_meta;
+    const rtd::Float4* boxes;   // 2 x Float4 per Box (device_types.h); in LDS behind the records when eb_boxes_on
     const rtd::Medium* media;
     const rtd::Xform* xforms;
     const rtd::Wrap* wraps;
@@ -45,25 +46,27 @@ struct SceneDev {
     const rtd::Float4* shade_blob; uint32_t shade_blob_bytes;   // 0: no staging
     // the same for k_extend's primitive pass on LDS-resident scenes: rects, moving spheres, transforms, media behind the records and the
     // sphere data (book-3 Cornell tests its 12 rects on every segment)
-    const rtd::Float4* ext_blob; uint32_t ext_blob_bytes; uint32_t eb_rects, eb_moving, eb_xforms, eb_media;
-    uint32_t eb_rect_stride;   // 32: the rect table as it is (sc.rects is redirected too); 24: without the two padding words, where only that fits
+    const rtd::Float4* ext_blob; uint32_t ext_blob_bytes; uint32_t eb_rects, eb_moving, eb_xforms, eb_media, eb_boxes;
+    uint32_t eb_rect_stride;   // 32: the rect table as it is (sc.rects is redirected too); 24: without the two padding words, where only that fits;
+                               // 0: the rect table is not staged (a scene whose rects are mostly box sides: the boxes are staged, a lone rect reads HBM)
     uint32_t sb_perlin_only;   // 1: the blob holds the Perlin tables alone (a scene whose other tables are too big to stage: book-2 final)
     uint32_t sb_spheres, sb_sphere_meta, sb_rects, sb_rect_meta, sb_moving, sb_moving_meta, sb_mat_a, sb_mat_b, sb_xforms, sb_wraps, sb_lights, sb_textures;   // byte offsets
 };
 
 // Path pool: structure of arrays, one lane-contiguous record per array and slot.
 //   ray_o = (origin.xyz, time)   ray_d = (direction.xyz, primitive the ray starts on)   hit = (t, primitive id), written by k_extend
-//   s0 = (T.rgb, work item)      s3 = (rng counter lo, hi, sample << 8 | depth)          s1 = (acc.rgb, -)  multi-sample items only
-// 60 bytes per path (+ 8 for the hit): T = throughput of the sample in flight, acc = sum over the finished samples of the current work
-// item. The radiance of the sample in flight needs no slot (kernels.hip PathState); the pixel is decoded from the work item.
+//   s0 = (T.rgb, work item)      sd = draws so far << 8 | depth                          s1 = (acc.rgb, sample)  multi-sample items only
+// 52 bytes per path (+ 8 for the hit): T = throughput of the sample in flight, acc = sum over the finished samples of the current work
+// item. The radiance of the sample in flight needs no slot (kernels.hip PathState); the pixel is decoded from the work item, and so is
+// the RNG state: a path's stream is a pure function of (seed, pixel, sample), so its base is recomputed from the work item and only
+// the NUMBER of draws made so far travels (round 2 carried the 64-bit counter itself: 60 bytes).
 // The pool is kQueues independent queues of queue_cap slots each (slot s of queue q = record q * queue_cap + s): paths stay in
 // their queue for life, every counter (pool size, queue head, next work item) exists once per queue, kQStride u32 = 128 bytes apart.
 // One counter pair for the whole pool made k_shade wait on same-address atomics (one per 512 paths, ~11 ns each: 29 ms of 39).
 constexpr uint32_t kQueues = 8, kQStride = 32;
-struct U3 { uint32_t x, y, z; };
 struct PoolDev {
     rtd::Float4* ray_o; rtd::Float4* ray_d; uint2* hit;
-    rtd::Float4* s0; U3* s3; rtd::Float4* s1;
+    rtd::Float4* s0; uint32_t* sd; rtd::Float4* s1;
 };
 
 // Exact u32 division by a launch-invariant divisor: q = (t + ((n - t) >> s1)) >> s2 with t = umulhi(m, n)
@@ -97,6 +100,7 @@ struct RenderDev {
     const uint32_t* tile_prefix;  // [n_local_tiles + 1]: in-image pixels in local tiles before lt
     uint32_t tile_slack;          // the tile of pixel q is within [q / ts^2, q / ts^2 + tile_slack] (edge tiles are clipped)
     FastDiv div_ts2, div_tiles_x, div_sq_row, div_item_tile;   // ts^2, tiles_x, ts / 8, ts^2 * n_blocks
+    FastDiv div_nblocks, div_width, div_ts, div_shards;        // n_blocks, width, tile_size, shard_count: a path's item id <-> pixel <-> its slot in blocksum
     rtd::Float4* blocksum;  // [total_items]: RGB sum of one work item's samples
 };
 

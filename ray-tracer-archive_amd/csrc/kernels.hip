@@ -99,9 +99,10 @@ DEVI uint64_t medium_bits(uint64_t base, uint32_t segment, uint32_t medium_id) {
     return fin(base ^ fin(0xA0761D6478BD642Full * (uint64_t)(segment + 1) + 0xE7037ED1A0B428DBull * (uint64_t)(medium_id + 1)));
 }
 DEVI float u01(uint64_t z) { return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f); }
+// `n` counts the draws made: a path's state between two kernels is (work item, n) — the base is recomputed (path_rng below)
 struct Rng {
-    uint64_t s;
-    DEVI uint64_t next64() { s += kGamma; return fin(s); }
+    uint64_t s; uint32_t n;
+    DEVI uint64_t next64() { s += kGamma; ++n; return fin(s); }
     DEVI float rnd() { return u01(next64()); }                               // rt_weekend.rs:8-11
     DEVI float range(float lo, float hi) { return lo + (hi - lo) * rnd(); }  // rt_weekend.rs:13-15
 };
@@ -274,7 +275,7 @@ DEVI V3 moving_center(Float4 m0, Float4 m1, Float4 m2, float time) {           /
 }
 // XyRect/XzRect/YzRect::hit (aarect.rs:31-48, 81-98, 150-167)
 DEVI bool rect_hit(V3 o, V3 d, Float4 r0, Float4 r1, float tmin, float tmax, float& t, float& ha, float& hb) {
-    const int kaxis = (int)r1.y & 3;      // + 4 on the first side of a box (scene_compile.cpp add_box_rects)
+    const int kaxis = (int)r1.y;
     const int ia = kaxis == 0 ? 1 : 0, ib = kaxis == 2 ? 1 : 2;
     const float tt = fdiv(r1.x - comp(o, kaxis), comp(d, kaxis));
     if (tt < tmin || tt > tmax) return false;
@@ -432,6 +433,28 @@ DEVI WorkItem decode_work(const RenderDev& rd, uint32_t w) {
     return it;
 }
 
+// A path names its work by the ITEM ID (pixel index * n_blocks + block): a pure function of (pixel, block), independent of tiling and
+// sharding, from which the RNG base — keyed by (pixel, sample) — is two multiplications away. Work items (the tile-ordered numbering
+// above) are what the queues deal out and what indexes blocksum; a path meets them only when it starts (decode_work) and when its
+// item's sum is stored (item_slot). Carrying the work item instead cost every shaded segment a tile search with two dependent loads.
+DEVI uint32_t item_id(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t blk) { return (y * rd.width + x) * rd.n_blocks + blk; }
+DEVI void item_pixel(const RenderDev& rd, uint32_t item, uint32_t& x, uint32_t& y, uint32_t& blk) {
+    const uint32_t pixel = fdivu(item, rd.div_nblocks);
+    blk = item - pixel * rd.n_blocks;
+    y = fdivu(pixel, rd.div_width); x = pixel - y * rd.width;
+}
+// slot of an item's sum in blocksum = its work item number (inverse of decode_work)
+DEVI uint32_t item_slot(const RenderDev& rd, uint32_t item) {
+    uint32_t x, y, blk; item_pixel(rd, item, x, y, blk);
+    const uint32_t tx = fdivu(x, rd.div_ts), ty = fdivu(y, rd.div_ts);
+    const uint32_t lt = fdivu(ty * rd.tiles_x + tx - rd.shard_index, rd.div_shards);
+    const uint32_t x0 = tx * rd.tile_size, y0 = ty * rd.tile_size, w = min(rd.tile_size, rd.width - x0), h = min(rd.tile_size, rd.height - y0);
+    const uint32_t px = x - x0, py = y - y0;
+    const bool full = w == rd.tile_size && h == rd.tile_size;
+    const uint32_t p = full ? (((py >> 3) * (rd.tile_size >> 3) + (px >> 3)) << 6) + ((py & 7u) << 3) + (px & 7u) : py * w + px;
+    return rd.tile_prefix[lt] * rd.n_blocks + blk * (w * h) + p;
+}
+
 // Work items beyond the pool's first fill (items 0 .. n_init-1) are dealt to the queues in runs of 64: queue q's t-th draw is item
 // n_init + ((t / 64) * kQueues + q) * 64 + t % 64 (so 64 consecutive draws of a queue still cover one 8x8 pixel square); valid while
 // below total_items. Which queue renders an item does not matter to the picture (per-item sums, RNG keyed by pixel and sample).
@@ -447,7 +470,7 @@ typedef float F2 __attribute__((ext_vector_type(2)));
 // per-ray constants of the slab test. Boxes are stored as centre c and half extent h (device_types.h: NodeDev): the ray
 // meets the slab of one axis at tc -+ th with tc = c/d - o/d and th = h/|d|, which needs no min/max to order the two
 // planes. Culling only: boxes carry the rounding slack (scene_compile.cpp pad + rt_api.cpp device_nodes).
-struct SlabRay { F2 inv_xy, noi_xy, ainv_xy, inv_z, noi_z; };   // inv_z = (1/d.z, |1/d.z|), noi_z = (-o.z/d.z, 0)
+struct SlabRay { F2 inv_xy, noi_xy, ainv_xy, e_xy, inv_z, noi_z; };   // inv_z = (1/d.z, |1/d.z|), noi_z = (-o.z/d.z, e_z); e: see set_slab_ray
 DEVI void set_slab_ray(V3 o, V3 d, SlabRay& r) {
     // A direction component of exactly 0 (a cosine-sampled bounce with r2 = 0 leaves the surface along its normal: one ray
     // in 2^24) would make 1/d infinite, c/d - o/d = inf - inf, and the ray would pass EVERY box: 1.5 M dependent visits in
@@ -458,7 +481,15 @@ DEVI void set_slab_ray(V3 o, V3 d, SlabRay& r) {
                       fminf(fmaxf(fast_rcp(d.z), -kInvMax), kInvMax));
     r.inv_xy = F2{inv.x, inv.y}; r.ainv_xy = F2{fabsf(inv.x), fabsf(inv.y)};
     r.noi_xy = F2{-(o.x * inv.x), -(o.y * inv.y)};
-    r.inv_z = F2{inv.z, fabsf(inv.z)}; r.noi_z = F2{-(o.z * inv.z), 0.f};
+    // e = the part of the test's own rounding that grows with the ray's ORIGIN, in units of t: 5 eps |o| |1/d| (rt_api.cpp node_boxes has
+    // the derivation and pays the record's part). It rides in the addend of the FMA that forms the half width, so it costs no instruction;
+    // and because it is the ray's own |o| — not the scene's extent, which round 2 padded every box with — a ray that leaves a box face
+    // 400 units from the origin sees that box end 1e-4 behind it, not 8e-3: below t_min, like the reference's exact box.
+    // (capped at half of |1/d|: the self-loop records mark "never passed" with h = -1, i.e. th = -|1/d| + e must stay negative; the cap
+    // binds only for |o| > 1.5e6, where f32 coordinates are good to a tenth of a unit anyway)
+    constexpr float kE = 5.5f * 5.9604645e-8f;
+    r.e_xy = F2{fminf(kE * fabsf(o.x), 0.5f) * fabsf(inv.x), fminf(kE * fabsf(o.y), 0.5f) * fabsf(inv.y)};
+    r.inv_z = F2{inv.z, fabsf(inv.z)}; r.noi_z = F2{-(o.z * inv.z), fminf(kE * fabsf(o.z), 0.5f) * fabsf(inv.z)};
 }
 #ifndef RT_CHUNK
 #define RT_CHUNK 1024       // rays a wave takes from the queue head per atomic (2^28 rays per launch: same-address atomics cost ~11 ns each)
@@ -512,18 +543,25 @@ struct PathState;
 enum : uint32_t { SH_FINISHED = 1u, SH_TIME_ZERO = 2u };
 template <uint32_t FEAT> DEVI uint32_t shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& d, float tm, PathState& s, Rng& g, uint32_t& depth, uint2 hit, V3& L,
                                                      unsigned long long& c_light_rect, unsigned long long& c_light_sphere);
-DEVI bool finish_sample(const RenderDev& rd, PathState& s, Rng& g, uint32_t& sample, uint32_t& depth, V3 L, V3& o, V3& d, float& tm);
-DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, V3& o, V3& d, float& tm);
+DEVI bool finish_sample(const RenderDev& rd, PathState& s, Rng& g, uint32_t& depth, V3 L, V3& o, V3& d, float& tm);
+DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, Rng& g, V3& o, V3& d, float& tm);
 // L, the radiance of the sample in flight, is not part of the state: `emitted` is non-zero only for
 // DiffuseLight, which never scatters (material.rs:12-14,184-190), and the background is returned on a miss
 // (main.rs:74-76) — so radiance is only ever added by the event that ENDS the path, in the same shading step
 // that folds it into `acc`.
 struct PathState {
     V3 T, acc;
-    uint32_t work, sdepth;       // sdepth = sample index << 8 | depth
+    uint32_t work, sample;       // the ITEM ID (item_id above, not the work item number) and the index of its sample in flight
     uint32_t from;               // primitive id the ray starts on (hit-record id), 0 = none
-    uint64_t rng;
 };
+// The RNG of the path that renders `sample` of the pixel of work item `work`, after `n` draws (rt_weekend.rs:8-19's stream, DESIGN "RNG contract")
+// `sample`: out — the stored index for a multi-sample item (with_acc), else the item's own block number (one sample per item)
+DEVI Rng path_rng(const RenderDev& rd, uint32_t item, bool with_acc, uint32_t stored_sample, uint32_t n, uint32_t& sample) {
+    const uint32_t pixel = fdivu(item, rd.div_nblocks), blk = item - pixel * rd.n_blocks;
+    sample = with_acc ? stored_sample : (blk << rd.block_shift);
+    Rng g; g.s = path_base(rd.seed, (uint64_t)pixel, sample) + (uint64_t)n * kGamma; g.n = n;
+    return g;
+}
 constexpr int kShadeBatch = 16;   // DRAIN: lanes on DONE that trigger a shading pass
 // (more resident waves do not help the HBM walk: the config-5 variant forced to 7 waves per SIMD, 72 VGPRs, runs 198.2 ms against 197.2 at
 // 6 waves, and 210.5 ms at 8 with 44 B of scratch)
@@ -603,7 +641,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     uint32_t slot = 0, node = C16 ? 0u : a_idle, hit_prim = rtd::HIT_NONE, from = 0;
     float tmax = kInf, tm = 0.f, a = 1.f;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
-    SlabRay sr; sr.inv_xy = sr.noi_xy = sr.ainv_xy = sr.inv_z = sr.noi_z = F2{0.f, 0.f};
+    SlabRay sr; sr.inv_xy = sr.noi_xy = sr.ainv_xy = sr.e_xy = sr.inv_z = sr.noi_z = F2{0.f, 0.f};
     V3 ow = o, dw = d;                 // world ray while inside an instance transform
     uint64_t mkey = 0; uint32_t seg = 0;
     unsigned long long c_nodes = 0, c_prims[RT_N_PRIM_TYPES_K] = {0, 0, 0, 0, 0, 0};
@@ -669,7 +707,17 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         else return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(nodes) + (off - top_bytes));
     };
     // rect `idx` of the primitive pass: a0 a1 b0 b1 | k axis, from the staged table (LDS address, stride 32 or 24) or from HBM
-    const uint32_t rects_lds = (LDS && sc.ext_blob_bytes != 0u) ? (2u * sc.n_records + sc.n_spheres) * 16u + sc.eb_rects : 0u, rect_stride = sc.eb_rect_stride;
+    const uint32_t blob_lds = (2u * sc.n_records + sc.n_spheres) * 16u;   // LDS address of the staged tables behind records and spheres
+    const uint32_t rects_lds = (LDS && sc.ext_blob_bytes != 0u && sc.eb_rect_stride != 0u) ? blob_lds + sc.eb_rects : 0u, rect_stride = sc.eb_rect_stride;
+    const bool boxes_in_lds = LDS && sc.ext_blob_bytes != 0u;
+    const uint32_t boxes_lds = blob_lds + sc.eb_boxes;
+    // Box `idx`: (x0, x1, y0, y1) (z0, z1, first side's rect index, -)
+    auto load_box = [&](uint32_t idx, float4& b0, float4& b1) {
+        if (boxes_in_lds) {
+            const F4V a0 = *reinterpret_cast<lds_f4>(boxes_lds + idx * 32u), a1 = *reinterpret_cast<lds_f4>(boxes_lds + idx * 32u + 16u);
+            b0 = make_float4(a0.x, a0.y, a0.z, a0.w); b1 = make_float4(a1.x, a1.y, a1.z, a1.w);
+        } else { const Float4 a0 = sc.boxes[2 * idx], a1 = sc.boxes[2 * idx + 1]; b0 = make_float4(a0.x, a0.y, a0.z, a0.w); b1 = make_float4(a1.x, a1.y, a1.z, a1.w); }
+    };
     auto load_rect = [&](uint32_t idx, Float4& r0, Float4& r1) {
         if (LDS && rects_lds != 0u) {
             const uint32_t at = rects_lds + idx * rect_stride;
@@ -678,12 +726,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             r1 = Float4{__uint_as_float(p2.x), __uint_as_float(p2.y), 0.f, 0.f};
         } else { r0 = sc.rects[2 * idx]; r1 = sc.rects[2 * idx + 1]; }
     };
-    auto load_rect_plane = [&](uint32_t idx) -> float {       // the plane coordinate k alone
-        if (LDS && rects_lds != 0u) return *reinterpret_cast<const __attribute__((address_space(3))) float*>(rects_lds + idx * rect_stride + 16u);
-        return sc.rects[2 * idx + 1].x;
-    };
     // ---- DRAIN: the lane's path, for its whole life ----
-    PathState ps{}; Rng g; g.s = 0; uint32_t depth = 0, sample = 0;
+    PathState ps{}; Rng g; g.s = 0; g.n = 0; uint32_t depth = 0;
     unsigned long long c_segments = 0, c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
     const bool with_acc = rd.block_shift != 0u;
     // the root list's every-ray members (SceneDev::prologue), for a lane whose walk begins: world space, t_max = inf
@@ -715,9 +759,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         a = len2(d);
         if (FEAT & F_XFORM) { ow = o; dw = d; }
         if (FEAT & F_MEDIUM) {
-            const WorkItem it = decode_work(rd, ps.work);
             seg = depth;
-            mkey = path_base(rd.seed, (uint64_t)it.y * rd.width + it.x, sample);
+            mkey = path_base(rd.seed, (uint64_t)fdivu(ps.work, rd.div_nblocks), ps.sample);
         }
         from = ps.from; tmax = kInf; hit_prim = rtd::HIT_NONE; go_root();
         prologue();
@@ -726,12 +769,13 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         const uint32_t i = (blockIdx.x / kQueues) * blockDim.x + threadIdx.x;
         if (i < count) {
             const Float4 ro = pool.ray_o[qbase + i], rdv = pool.ray_d[qbase + i], s0 = pool.s0[qbase + i];
-            const U3 s3 = pool.s3[qbase + i];
+            const uint32_t sd = pool.sd[qbase + i];
             o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
-            ps.T = v3(s0.x, s0.y, s0.z); ps.work = __float_as_uint(s0.w); ps.sdepth = s3.z; ps.from = __float_as_uint(rdv.w);
-            if (with_acc) { const Float4 s1 = pool.s1[qbase + i]; ps.acc = v3(s1.x, s1.y, s1.z); }
-            g.s = (uint64_t)s3.x | ((uint64_t)s3.y << 32);
-            depth = ps.sdepth & 0xFFu; sample = ps.sdepth >> 8;
+            ps.T = v3(s0.x, s0.y, s0.z); ps.work = __float_as_uint(s0.w); ps.from = __float_as_uint(rdv.w);
+            uint32_t stored = 0u;
+            if (with_acc) { const Float4 s1 = pool.s1[qbase + i]; ps.acc = v3(s1.x, s1.y, s1.z); stored = __float_as_uint(s1.w); }
+            depth = sd & 0xFFu;
+            g = path_rng(rd, ps.work, with_acc, stored, sd >> 8, ps.sample);
             begin_walk();
         }
     }
@@ -762,10 +806,10 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     if (FEAT & F_XFORM) { ow = o; dw = d; }
                     if (FEAT & F_MEDIUM) {
                         // the free-path draws are keyed by the path's RNG base: pixel from the work item, sample from the state word
-                        const uint32_t sd = pool.s3[qbase + slot].z;
-                        const WorkItem it = decode_work(rd, __float_as_uint(pool.s0[qbase + slot].w));
-                        seg = sd & 0xFFu;
-                        mkey = path_base(rd.seed, (uint64_t)it.y * rd.width + it.x, sd >> 8);
+                        const uint32_t item = __float_as_uint(pool.s0[qbase + slot].w), pixel = fdivu(item, rd.div_nblocks);
+                        seg = pool.sd[qbase + slot] & 0xFFu;
+                        const uint32_t smp = rd.block_shift != 0u ? __float_as_uint(pool.s1[qbase + slot].w) : (item - pixel * rd.n_blocks);
+                        mkey = path_base(rd.seed, (uint64_t)pixel, smp);
                     }
                     tmax = kInf; hit_prim = rtd::HIT_NONE; go_root();   // address 0 = the root (the first record, or its copy in the top)
                     prologue();
@@ -809,7 +853,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             // one packed FMA + add/sub for z. min3/max3 ignore a NaN operand (0*inf), which keeps the box — conservative,
             // like the reference. A record without a box has h = inf; a self-loop record has h < 0 and both links on itself.
             const F2 tc = __builtin_elementwise_fma(F2{n0.x, n0.y}, sr.inv_xy, sr.noi_xy);   // (tcx, tcy)
-            const F2 th = F2{n0.z, n0.w} * sr.ainv_xy;                                         // (thx, thy)
+            const F2 th = __builtin_elementwise_fma(F2{n0.z, n0.w}, sr.ainv_xy, sr.e_xy);      // (thx, thy), widened by the ray's own rounding
             const F2 tz = __builtin_elementwise_fma(F2{n1.x, n1.y}, sr.inv_z, sr.noi_z);      // (tcz, thz)
             const F2 lo = tc - th, hi = tc + th;
             const float tnear = fmaxf(fmaxf(lo.x, lo.y), fmaxf(tz.x - tz.y, kTMin));
@@ -875,12 +919,12 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         auto move_on = [&]() { if (C16) pend = 0u; else node = resume; };   // past the leaf the lane was parked with
         if (FEAT & F_XFORM) {
             const uint32_t type = pl >> 28;
-            if (type == rtd::LT_ENTER || type == rtd::LT_EXIT) {   // Translate/RotateY::hit: switch ray space, move on
-                const uint32_t xf = pl & rtd::LEAF_MAX_FIRST;
+            if (type == rtd::LT_XFORM) {   // Translate/RotateY::hit: switch ray space, move on
+                const uint32_t xf = pl & 0xFFFFu;
                 if (xf == 0u) { o = ow; d = dw; }
                 else xform_ray(sc.xforms[xf], ow, dw, o, d);
                 if (C16) set_grid_ray(); else set_slab_ray(o, d, sr);
-                if (COUNT) { if (type == rtd::LT_ENTER) c_prims[5]++; }
+                if (COUNT) { if ((pl & rtd::XFORM_EXIT) == 0u) c_prims[5]++; }
                 pl = 0u; move_on();
             }
         }
@@ -908,7 +952,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             const uint32_t ty = pl >> 28;
             uint32_t best = 0u;
 #pragma unroll
-            for (uint32_t k = rtd::LT_SPHERE; k <= rtd::LT_MEDIUM; ++k) {
+            for (uint32_t k = rtd::LT_SPHERE; k <= rtd::LT_BOX; ++k) {
+                if (k == rtd::LT_XFORM) continue;
                 const uint32_t c = (uint32_t)__popcll(__ballot(ty == k));
                 if (c > best) { best = c; serve = k; }
             }
@@ -968,25 +1013,25 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     if (h) { tmax = t; hit_prim = id; }
                 }
             } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
-                for (uint32_t k = 0; k < cnt;) {
+                for (uint32_t k = 0; k < cnt; ++k) {
                     Float4 r0, r1;
                     load_rect(first + k, r0, r1);
                     const uint32_t id = (rtd::LT_RECT << 28) | (first + k);
-                    if ((int)r1.y >= 4) {
-                        // the six sides of a box, all of them in this leaf: every bound is in the first side's record but z0
-                        const float z0 = load_rect_plane(first + k + 1u);
-                        if (COUNT) c_prims[2] += 6ull;
-                        uint32_t which;
-                        if (box_sides_hit(o, d, r0.x, r0.y, r0.z, r0.w, z0, r1.x, kTMin, tmax, from - id, which)) hit_prim = id + which;
-                        k += 6u;
-                    } else {
-                        float t, ha, hb;
-                        if (COUNT) c_prims[2]++;
-                        // a ray that starts on this rect's plane meets it at t = 0 < t_min exactly; in f32 (after an
-                        // instance transform's round trip) t = rounding / d_k can pass t_min
-                        if (id != from && rect_hit(o, d, r0, r1, kTMin, tmax, t, ha, hb)) { tmax = t; hit_prim = id; }
-                        k += 1u;
-                    }
+                    float t, ha, hb;
+                    if (COUNT) c_prims[2]++;
+                    // a ray that starts on this rect's plane meets it at t = 0 < t_min exactly; in f32 (after an
+                    // instance transform's round trip) t = rounding / d_k can pass t_min
+                    if (id != from && rect_hit(o, d, r0, r1, kTMin, tmax, t, ha, hb)) { tmax = t; hit_prim = id; }
+                }
+            } else if ((FEAT & F_RECT) && type == rtd::LT_BOX) {
+                // Box::hit (boxes.rs:77-79: the list of its six sides), from the box's own record; the hit names the side's rect
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    float4 b0, b1;
+                    load_box(first + k, b0, b1);
+                    const uint32_t id = (rtd::LT_RECT << 28) | __float_as_uint(b1.z);
+                    if (COUNT) c_prims[2] += 6ull;
+                    uint32_t which;
+                    if (box_sides_hit(o, d, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, kTMin, tmax, from - id, which)) hit_prim = id + which;
                 }
             } else if ((FEAT & F_MOVING) && type == rtd::LT_MOVING) {
                 for (uint32_t k = 0; k < cnt; ++k) {
@@ -1032,8 +1077,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     if (sh & SH_TIME_ZERO) tm = 0.0f;
                     if (sh & SH_FINISHED) {
                         if (COUNT) c_samples++;
-                        if (finish_sample(rd, ps, g, sample, depth, L, so, sd, tm)) {
-                            rd.blocksum[ps.work] = Float4{ps.acc.x, ps.acc.y, ps.acc.z, 0.f};
+                        if (finish_sample(rd, ps, g, depth, L, so, sd, tm)) {
+                            rd.blocksum[item_slot(rd, ps.work)] = Float4{ps.acc.x, ps.acc.y, ps.acc.z, 0.f};
                             want = true;
                         }
                     }
@@ -1047,7 +1092,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     base = (uint32_t)__shfl((int)base, __builtin_ctzll(wm));
                     if (want) {
                         const uint32_t work = queue_item(rd, q, base + lane_rank(wm));
-                        if (work < rd.total_items) { start_item(rd, work, ps, o, d, tm); g.s = ps.rng; depth = 0; sample = ps.sdepth >> 8; }
+                        if (work < rd.total_items) { start_item(rd, work, ps, g, o, d, tm); depth = 0; }
                         else go_idle();                                      // nothing left: the lane retires
                     }
                 }
@@ -1105,7 +1150,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 // One new sample: jitter (main.rs:752-753) then Camera::get_ray (camera.rs:60-70).
 DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t sample, Rng& g, V3& o, V3& d, float& tm) {
     const uint64_t pixel_index = (uint64_t)y * rd.width + x;
-    g.s = path_base(rd.seed, pixel_index, sample);
+    g.s = path_base(rd.seed, pixel_index, sample); g.n = 0u;
     const float ju = g.rnd(), jv = g.rnd();
     const uint32_t j = rd.height - 1u - y;                       // main.rs:733
     const float u = fdiv((float)x + ju, (float)(rd.width - 1u));    // main.rs:752
@@ -1125,15 +1170,15 @@ DEVI void new_camera_ray(const RenderDev& rd, uint32_t x, uint32_t y, uint32_t s
     tm = g.range(rd.cam_time0, rd.cam_time1);                    // drawn even when time0 == time1
 }
 
-// 60 bytes per path: ray_o, ray_d, s0 = (T, work item), s3 = (rng, sample << 8 | depth) — the pixel is a function of the work item and is
-// decoded where it is needed (a new sample of a multi-sample item, the key of the medium draws), not carried; the running sum
-// `acc` (s1, +16 bytes) exists only when a work item is more than one sample (with_acc = block_shift != 0).
-DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const PathState& s, bool with_acc) {
+// 52 bytes per path: ray_o, ray_d, s0 = (T, work item), sd = draws << 8 | depth — the pixel is a function of the work item and is decoded
+// where it is needed (the RNG base, a new sample of a multi-sample item, the key of the medium draws), not carried; the running sum
+// `acc` and the sample index (s1, +16 bytes) exist only when a work item is more than one sample (with_acc = block_shift != 0).
+DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const PathState& s, uint32_t draws, uint32_t depth, bool with_acc) {
     p.ray_o[i] = Float4{o.x, o.y, o.z, tm};
     p.ray_d[i] = Float4{d.x, d.y, d.z, __uint_as_float(s.from)};
     p.s0[i] = Float4{s.T.x, s.T.y, s.T.z, __uint_as_float(s.work)};
-    p.s3[i] = U3{(uint32_t)s.rng, (uint32_t)(s.rng >> 32), s.sdepth};
-    if (with_acc) p.s1[i] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
+    p.sd[i] = (draws << 8) | depth;
+    if (with_acc) p.s1[i] = Float4{s.acc.x, s.acc.y, s.acc.z, __uint_as_float(s.sample)};
 }
 
 // Workgroup-aggregated allocation: every thread of the block calls it; threads with `flag` get
@@ -1159,13 +1204,12 @@ DEVI uint32_t block_alloc(bool flag, uint32_t* counter, uint32_t* s_scan) {
 }
 
 // A fresh path for work item `work` (first sample of its block).
-DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, V3& o, V3& d, float& tm) {
+DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, Rng& g, V3& o, V3& d, float& tm) {
     const WorkItem it = decode_work(rd, work);
-    Rng g;
     const uint32_t sample = it.blk << rd.block_shift;
     new_camera_ray(rd, it.x, it.y, sample, g, o, d, tm);
     s.T = v3(1, 1, 1); s.acc = v3(0, 0, 0);
-    s.work = work; s.sdepth = sample << 8; s.rng = g.s; s.from = 0u;
+    s.work = item_id(rd, it.x, it.y, it.blk); s.sample = sample; s.from = 0u;
 }
 
 __global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, RenderDev rd, uint32_t n_init, uint32_t* __restrict__ next_work, uint32_t* __restrict__ out_count) {
@@ -1179,10 +1223,10 @@ __global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, Render
         next_work[i * kQStride] = 0u;
     }
     if (i < n_init) {
-        PathState s; V3 o, d; float tm;
-        start_item(rd, i, s, o, d, tm);
+        PathState s; V3 o, d; float tm; Rng g;
+        start_item(rd, i, s, g, o, d, tm);
         const uint32_t q = (i >> 9) & (kQueues - 1u), slot = ((i / (512u * kQueues)) << 9) | (i & 511u);
-        store_path(pool, q * rd.queue_cap + slot, o, d, tm, s, rd.block_shift != 0u);
+        store_path(pool, q * rd.queue_cap + slot, o, d, tm, s, g.n, 0u, rd.block_shift != 0u);
     }
 }
 
@@ -1483,14 +1527,14 @@ DEVI uint32_t shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& 
 
 // The end of a sample (main.rs:772 `pixel_color += received`): fold L into the work item's sum, move to the item's next sample or
 // report the item complete (true; the caller stores s.acc and draws new work).
-DEVI bool finish_sample(const RenderDev& rd, PathState& s, Rng& g, uint32_t& sample, uint32_t& depth, V3 L, V3& o, V3& d, float& tm) {
+DEVI bool finish_sample(const RenderDev& rd, PathState& s, Rng& g, uint32_t& depth, V3 L, V3& o, V3& d, float& tm) {
     const bool fin_ok = (fabsf(L.x) < kInf) && (fabsf(L.y) < kInf) && (fabsf(L.z) < kInf);
     if (!fin_ok && rd.nan_policy == RT_NAN_PER_SAMPLE_K) L = v3(0.f, 0.f, 0.f);
     s.acc = s.acc + L;
-    sample++;
+    const uint32_t sample = ++s.sample;
     if ((sample & ((1u << rd.block_shift) - 1u)) != 0u && sample < rd.spp) {
-        const WorkItem it = decode_work(rd, s.work);
-        new_camera_ray(rd, it.x, it.y, sample, g, o, d, tm);   // next sample of the same block
+        uint32_t x, y, blk; item_pixel(rd, s.work, x, y, blk);
+        new_camera_ray(rd, x, y, sample, g, o, d, tm);   // next sample of the same block
         s.T = v3(1, 1, 1); depth = 0; s.from = 0u;
         return false;
     }
@@ -1558,16 +1602,17 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     PathState s{}; V3 o = v3(0, 0, 0), d = v3(0, 0, 1); float tm = 0.f;
     unsigned long long c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
     bool want_work = false;
+    Rng g; g.s = 0; g.n = 0u; uint32_t depth = 0u;
     if (alive) {
         const Float4 ro = in.ray_o[qbase + i], rdv = in.ray_d[qbase + i], s0 = in.s0[qbase + i];
-        const U3 s3 = in.s3[qbase + i]; const uint2 hit = in.hit[qbase + i];
+        const uint32_t sd = in.sd[qbase + i]; const uint2 hit = in.hit[qbase + i];
         o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
-        s.T = v3(s0.x, s0.y, s0.z); s.work = __float_as_uint(s0.w); s.sdepth = s3.z;
-        if (with_acc) { const Float4 s1 = in.s1[qbase + i]; s.acc = v3(s1.x, s1.y, s1.z); }   // else 0: the item is this one sample
+        s.T = v3(s0.x, s0.y, s0.z); s.work = __float_as_uint(s0.w);
+        uint32_t stored = 0u;
+        if (with_acc) { const Float4 s1 = in.s1[qbase + i]; s.acc = v3(s1.x, s1.y, s1.z); stored = __float_as_uint(s1.w); }   // else acc = 0: the item is this one sample
         V3 L = v3(0.f, 0.f, 0.f);          // radiance of this sample: set by the terminal event only
-        s.rng = (uint64_t)s3.x | ((uint64_t)s3.y << 32);
-        Rng g; g.s = s.rng;
-        uint32_t depth = s.sdepth & 0xFFu, sample = s.sdepth >> 8;
+        depth = sd & 0xFFu;
+        g = path_rng(rd, s.work, with_acc, stored, sd >> 8, s.sample);     // the stream is a function of (pixel, sample): only the draw count travels
         const uint32_t sh = shade_segment<FEAT>(sc, rd, o, d, tm, s, g, depth, hit, L, c_light_rect, c_light_sphere);
         const bool finished = (sh & SH_FINISHED) != 0u;
         if (sh & SH_TIME_ZERO) tm = 0.0f;
@@ -1575,13 +1620,11 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
         if (finished) {
             // one sample done
             if (COUNT) c_samples++;
-            if (finish_sample(rd, s, g, sample, depth, L, o, d, tm)) {
-                rd.blocksum[s.work] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
+            if (finish_sample(rd, s, g, depth, L, o, d, tm)) {
+                rd.blocksum[item_slot(rd, s.work)] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
                 want_work = true;
             }
         }
-        s.rng = g.s;
-        s.sdepth = (sample << 8) | depth;
     }
 
     // ---- regeneration: a slot whose block is complete draws a new work item (one atomic per workgroup) ----
@@ -1589,7 +1632,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
         const uint32_t t = block_alloc(want_work, next_work, s_scan);
         if (want_work) {
             const uint32_t work = queue_item(rd, q, t);
-            if (work < rd.total_items) start_item(rd, work, s, o, d, tm);
+            if (work < rd.total_items) { start_item(rd, work, s, g, o, d, tm); depth = 0u; }
             else alive = false;
         }
     }
@@ -1597,7 +1640,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     // ---- compaction: survivors go to the other pool densely (wave64 ballot + prefix, LDS scan across waves) ----
     {
         const uint32_t dst = block_alloc(alive, count_out, s_scan);
-        if (alive) store_path(out, qbase + dst, o, d, tm, s, with_acc);
+        if (alive) store_path(out, qbase + dst, o, d, tm, s, g.n, depth, with_acc);
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { c_samples += __shfl_down(c_samples, off); c_light_rect += __shfl_down(c_light_rect, off); c_light_sphere += __shfl_down(c_light_sphere, off); }

@@ -167,14 +167,13 @@ struct DevNodes {
     uint32_t records() const { return n + 2u + n_twins; }
 };
 static void node_boxes(const std::vector<rtd::Node>& nodes, std::vector<rtd::NodeDev>& out) {
-    // boxes as centre c and half extent h, rounded outwards: [c-h, c+h] contains the (padded) host box plus the slack of the device's
-    // three roundings (tc, th, tc -+ th; ~3e-7 * (|c| + |o|) in space, |o| <= extent like scene_compile.cpp assumes)
+    // Boxes as centre c and half extent h with [c-h, c+h] containing the host box, plus the part of the device's rounding that grows with
+    // the RECORD's own coordinates. The slab test (kernels.hip) computes per axis tc = fma(c, 1/d, -(o/d)), th = h*|1/d| (+ e), tc -+ th:
+    // five roundings and a 1-ulp reciprocal, in all at most eps*|1/d|*(5|o| + 4(|c| + h)) with eps = 2^-24. The (|c| + h) part is paid here,
+    // per record: h grows by 4 eps (|c| + h) — 1e-4 units for a box 500 units from the origin; the |o| part is the ray's (set_slab_ray: e).
+    // Together they stay far below t_min * |d| (0.001), so a ray leaving a box face does not pass that box again, as in the reference.
     const float inf = std::numeric_limits<float>::infinity();
-    double extent = 0.0;
-    for (const rtd::Node& n : nodes) for (int a = 0; a < 3; ++a) {
-        if (std::isfinite(n.mn[a])) extent = std::max(extent, (double)std::fabs(n.mn[a]));
-        if (std::isfinite(n.mx[a])) extent = std::max(extent, (double)std::fabs(n.mx[a]));
-    }
+    constexpr double kEps = 5.9604644775390625e-8;
     out.resize(nodes.size());
     for (size_t i = 0; i < nodes.size(); ++i) {
         const rtd::Node& n = nodes[i];
@@ -183,7 +182,7 @@ static void node_boxes(const std::vector<rtd::Node>& nodes, std::vector<rtd::Nod
             if (!std::isfinite(n.mn[a]) || !std::isfinite(n.mx[a])) { c[a] = 0.f; h[a] = inf; continue; }   // a record without a box is always passed
             c[a] = (float)(0.5 * ((double)n.mn[a] + (double)n.mx[a]));
             double hd = std::max((double)n.mx[a] - (double)c[a], (double)c[a] - (double)n.mn[a]);
-            hd = hd * (1.0 + 1e-6) + 5e-7 * (std::fabs((double)c[a]) + extent);
+            hd += 4.5 * kEps * (std::fabs((double)c[a]) + hd);
             float hf = (float)hd; if ((double)hf < hd) hf = std::nextafterf(hf, inf);
             h[a] = hf;
         }
@@ -395,7 +394,7 @@ struct rti::SceneImage {
     bool in_lds = false, c16 = false, top = false;
     uint32_t oct_stride = 0u, oct_mask = 7u;
     std::vector<unsigned char> blob, eblob;
-    uint32_t sb[12] = {0}, perlin_only = 0u, eb[4] = {0}, eb_rect_stride = 32u;
+    uint32_t sb[12] = {0}, perlin_only = 0u, eb[5] = {0}, eb_rect_stride = 32u;
     uint32_t features = 0u;
 };
 void rti::scene_image_free(SceneImage* im) { delete im; }
@@ -458,16 +457,19 @@ int rti::scene_image_build(const RtSceneDesc* desc, const RtUploadOptions* optio
     }
     // k_extend's primitive pass tables for LDS-resident scenes (kernels.h SceneDev::ext_blob): small ones only, inside the LDS budget
     if (im->in_lds && opt.extend_lds_tables && !(cs.rects.empty() && cs.moving.empty() && cs.media.empty())) {
-        // staged once per workgroup and launch (persistent waves), so size only matters against the 160 KB of the CU: the rect table as
-        // it is (2 x 16 B per rect) where that fits, else without its two padding words (book-2 final scene: 2401 rects behind 91 KB of
-        // records and spheres)
+        // staged once per workgroup and launch (persistent waves), so size only matters against the 160 KB of the CU: the box records
+        // (32 B per Box) always; the rect table as it is (2 x 16 B per rect) where that fits too, else without its two padding words, else
+        // not at all — in a scene whose rects are the sides of boxes (book-2 final: 2400 of 2401) the walk never reads them, and the one
+        // lone rect comes from HBM/L2
         std::vector<unsigned char>& eblob = im->eblob; uint32_t* eb = im->eb;
         const size_t room = 160 * 1024 - lds_scene_bytes(cs);
         const size_t n_rects = cs.rects.size() / 2;
-        for (uint32_t stride : {32u, 24u}) {
+        for (uint32_t stride : {32u, 24u, 0u}) {
             eblob.clear();
             auto put = [&](const void* p, size_t bytes) { const uint32_t at = (uint32_t)eblob.size(); eblob.resize((eblob.size() + bytes + 15) & ~(size_t)15, 0); if (bytes) std::memcpy(eblob.data() + at, p, bytes); return at; };
-            if (stride == 32u) eb[0] = put(cs.rects.data(), n_rects * 32);
+            eb[4] = put(cs.boxes.data(), cs.boxes.size() * 16);
+            if (stride == 0u) eb[0] = 0u;
+            else if (stride == 32u) eb[0] = put(cs.rects.data(), n_rects * 32);
             else {
                 std::vector<float> packed(n_rects * 6);
                 for (size_t i = 0; i < n_rects; ++i) { std::memcpy(&packed[6 * i], &cs.rects[2 * i], 16); std::memcpy(&packed[6 * i + 4], &cs.rects[2 * i + 1], 8); }
@@ -495,7 +497,7 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     if (im.top) up(s->top_nodes, im.dn.top);
     if (im.c16) up(s->nodes, im.n16); else up(s->nodes, im.dn.main);
     up(s->spheres, cs.spheres); up(s->sphere_meta, cs.sphere_meta); up(s->moving, cs.moving); up(s->moving_meta, cs.moving_meta);
-    up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->media, cs.media);
+    up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->boxes, cs.boxes); up(s->media, cs.media);
     up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
     up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
     if (!im.blob.empty()) up(s->shade_blob, im.blob);
@@ -511,11 +513,11 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     d.n_prologue = (uint32_t)cs.prologue.size();
     for (uint32_t k = 0; k < rtd::MAX_PROLOGUE; ++k) d.prologue[k] = k < cs.prologue.size() ? cs.prologue[k] : 0u;
     d.n_prim_kinds = (cs.sphere_meta.empty() ? 0u : 1u) + (cs.moving_meta.empty() ? 0u : 1u) + (cs.rect_meta.empty() ? 0u : 1u) +
-                     (cs.tri_meta.empty() ? 0u : 1u) + (cs.media.empty() ? 0u : 1u);
+                     (cs.tri_meta.empty() ? 0u : 1u) + (cs.media.empty() ? 0u : 1u);   // (a Box counts with the rects: their sides)
     d.spheres = (const rtd::Float4*)s->spheres.p; d.sphere_meta = (const uint32_t*)s->sphere_meta.p; d.n_spheres = (uint32_t)cs.spheres.size();
     d.moving = (const rtd::Float4*)s->moving.p; d.moving_meta = (const uint32_t*)s->moving_meta.p;
     d.rects = (const rtd::Float4*)s->rects.p; d.rect_meta = (const uint32_t*)s->rect_meta.p;
-    d.tris = (const rtd::Float4*)s->tris.p; d.tri_meta = (const uint32_t*)s->tri_meta.p;
+    d.tris = (const rtd::Float4*)s->tris.p; d.tri_meta = (const uint32_t*)s->tri_meta.p; d.boxes = (const rtd::Float4*)s->boxes.p;
     d.media = (const rtd::Medium*)s->media.p; d.xforms = (const rtd::Xform*)s->xforms.p; d.wraps = (const rtd::Wrap*)s->wraps.p;
     d.mat_a = (const rtd::Float4*)s->mat_a.p; d.mat_b = (const uint32_t*)s->mat_b.p;
     d.textures = (const rtd::Texture*)s->textures.p; d.perlins = (const rtd::PerlinTable*)s->perlins.p;
@@ -524,7 +526,7 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     d.shade_blob = im.blob.empty() ? nullptr : (const rtd::Float4*)s->shade_blob.p; d.shade_blob_bytes = (uint32_t)im.blob.size();
     d.sb_spheres = sb[0]; d.sb_sphere_meta = sb[1]; d.sb_rects = sb[2]; d.sb_rect_meta = sb[3]; d.sb_moving = sb[4]; d.sb_moving_meta = sb[5];
     d.ext_blob = im.eblob.empty() ? nullptr : (const rtd::Float4*)s->ext_blob.p; d.ext_blob_bytes = (uint32_t)im.eblob.size();
-    d.eb_rect_stride = im.eb_rect_stride; d.eb_rects = eb[0]; d.eb_moving = eb[1]; d.eb_xforms = eb[2]; d.eb_media = eb[3];
+    d.eb_rect_stride = im.eb_rect_stride; d.eb_rects = eb[0]; d.eb_moving = eb[1]; d.eb_xforms = eb[2]; d.eb_media = eb[3]; d.eb_boxes = eb[4];
     d.sb_perlin_only = im.perlin_only;
     d.sb_mat_a = sb[6]; d.sb_mat_b = sb[7]; d.sb_xforms = sb[8]; d.sb_wraps = sb[9]; d.sb_lights = sb[10]; d.sb_textures = sb[11];
     s->features = im.features;
@@ -554,7 +556,7 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene) { 
 int rt_scene_destroy(RtCtx* ctx, RtScene* s) {
     if (!s) return RT_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
-    DevBuf* all[] = {&s->nodes, &s->spheres, &s->sphere_meta, &s->moving, &s->moving_meta, &s->rects, &s->rect_meta, &s->tris, &s->tri_meta, &s->media,
+    DevBuf* all[] = {&s->nodes, &s->spheres, &s->sphere_meta, &s->moving, &s->moving_meta, &s->rects, &s->rect_meta, &s->tris, &s->tri_meta, &s->boxes, &s->media,
                      &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights, &s->top_nodes, &s->shade_blob, &s->ext_blob};
     for (DevBuf* b : all) b->release();
     delete s;
@@ -618,6 +620,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     rd.n_local_tiles = tl.n_local;
     {   // launch-invariant divisors of the item -> (tile, pixel, sample) decode, and how far clipped edge tiles can move a tile index
         const uint64_t ts2 = (uint64_t)tl.ts * tl.ts, item_tile = ts2 * rd.n_blocks;
+        rd.div_nblocks = rtk::make_fastdiv(rd.n_blocks); rd.div_width = rtk::make_fastdiv(prm->width); rd.div_ts = rtk::make_fastdiv(tl.ts); rd.div_shards = rtk::make_fastdiv(sc);
         rd.div_ts2 = rtk::make_fastdiv((uint32_t)ts2); rd.div_tiles_x = rtk::make_fastdiv(tl.tiles_x); rd.div_sq_row = rtk::make_fastdiv(std::max(1u, tl.ts >> 3));
         const bool fits = item_tile <= 0xFFFFFFFFull;
         rd.div_item_tile = rtk::make_fastdiv(fits ? (uint32_t)item_tile : 0xFFFFFFFFu);
@@ -631,7 +634,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
 
     // Pool: as many paths in flight as there are work items, up to 2^28 (45 GB for the two pools) and to what the
     // device has free. Launches then carry hundreds of millions of rays: few launches, short tails.
-    const size_t rec[6] = {16, 16, 8, 16, 12, block_shift ? (size_t)16 : (size_t)0};   // ray_o ray_d hit s0 s3 [s1 = acc]
+    const size_t rec[6] = {16, 16, 8, 16, 4, block_shift ? (size_t)16 : (size_t)0};   // ray_o ray_d hit s0 sd [s1 = acc, sample]
     size_t slot_bytes = 0; for (int a = 0; a < 6; ++a) slot_bytes += 2 * rec[a];
     uint32_t P = prm->pool_slots ? prm->pool_slots : (1u << 28);
     P = (uint32_t)std::min<uint64_t>(P, total_items);
@@ -652,7 +655,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     for (int k = 0; k < 2; ++k) {
         for (int a = 0; a < 6; ++a) if (rec[a]) HIP_TRY(ctx, ctx->pool[k][a].ensure((size_t)P * rec[a]));
         pd[k].ray_o = (rtd::Float4*)ctx->pool[k][0].p; pd[k].ray_d = (rtd::Float4*)ctx->pool[k][1].p; pd[k].hit = (uint2*)ctx->pool[k][2].p;
-        pd[k].s0 = (rtd::Float4*)ctx->pool[k][3].p; pd[k].s3 = (rtk::U3*)ctx->pool[k][4].p; pd[k].s1 = rec[5] ? (rtd::Float4*)ctx->pool[k][5].p : nullptr;
+        pd[k].s0 = (rtd::Float4*)ctx->pool[k][3].p; pd[k].sd = (uint32_t*)ctx->pool[k][4].p; pd[k].s1 = rec[5] ? (rtd::Float4*)ctx->pool[k][5].p : nullptr;
     }
     HIP_TRY(ctx, ctx->blocksum.ensure((size_t)total_items * 16));
     rd.blocksum = (rtd::Float4*)ctx->blocksum.p;

@@ -48,7 +48,7 @@ struct RtCtx {
 };
 
 struct RtScene {
-    rti::DevBuf nodes, spheres, sphere_meta, moving, moving_meta, rects, rect_meta, tris, tri_meta, media, xforms, wraps, mat_a, mat_b, textures, perlins, images,
+    rti::DevBuf nodes, spheres, sphere_meta, moving, moving_meta, rects, rect_meta, tris, tri_meta, boxes, media, xforms, wraps, mat_a, mat_b, textures, perlins, images,
         image_bytes, lights, top_nodes, shade_blob, ext_blob;
     rtk::SceneDev dev{};
     uint32_t features = 0; bool in_lds = false;

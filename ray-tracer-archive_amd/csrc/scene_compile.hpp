@@ -14,6 +14,7 @@ struct CompiledScene {
     std::vector<rtd::Float4> moving;   std::vector<uint32_t> moving_meta;    // 3 per primitive
     std::vector<rtd::Float4> rects;    std::vector<uint32_t> rect_meta;      // 2 per primitive
     std::vector<rtd::Float4> tris;     std::vector<uint32_t> tri_meta;       // 3 per primitive
+    std::vector<rtd::Float4> boxes;                                          // 2 per Box (device_types.h): bounds + index of its first side in rects
     std::vector<rtd::Medium> media;
     std::vector<rtd::Xform> xforms;                                          // [0] = identity
     std::vector<rtd::Wrap> wraps;                                            // [0] = no wrappers

