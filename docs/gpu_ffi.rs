@@ -113,8 +113,8 @@ pub const RT_LAYOUT_SCENE_IN_HBM: u32 = 32;
 pub const RT_LAYOUT_NODES_32B: u32 = 64;
 pub const RT_LAYOUT_NO_SHADE_TABLES_IN_LDS: u32 = 128;
 pub const RT_LAYOUT_NO_EXTEND_TABLES_IN_LDS: u32 = 256;
-pub const RT_LAYOUT_BINARY_NODES: u32 = 512;
-pub const RT_LAYOUT_REFERENCE_COUNTERS: u32 = 1 | 4 | 16 | 512;   // RtStats test counts = the reference's own
+pub const RT_LAYOUT_WIDE_NODES: u32 = 512;
+pub const RT_LAYOUT_REFERENCE_COUNTERS: u32 = 1 | 4 | 16;   // RtStats test counts = the reference's own
 #[repr(C)] #[derive(Clone, Copy, Default, Debug)]
 pub struct RtUploadOptions {
     pub struct_bytes: u32, pub layout_flags: u32, pub lds_top_records: u32, pub octant_axes: u32, pub leaf_collapse: u32, pub list_park_cost: f32,
@@ -128,6 +128,12 @@ pub struct RtStats {
     pub iterations: u32, pub extend_launches: u32, pub shade_launches: u32, pub pool_slots: u32,
     pub scene_nodes: u64, pub scene_prims: u64, pub scene_bytes: u64, pub bvh_in_lds: u32, pub _pad: u32, pub debug: [u64; 8],
     pub gather_ms: f64, pub n_devices: u32, pub lds_top_nodes: u32, pub drain_ms: f64, pub drain_paths: u32, pub _pad2: u32,
+}
+
+#[repr(C)] #[derive(Clone, Copy, Default, Debug)]
+pub struct RtWideInfo {
+    pub n_nodes: u64, pub n_leaf_entries: u64, pub n_inner_entries: u64, pub n_prims: u64, pub depth: u32, pub _pad: u32,
+    pub mean_children: f64, pub mean_leaf_members: f64,
 }
 
 #[repr(C)] #[derive(Clone, Copy, Default, Debug)]
@@ -201,6 +207,7 @@ extern "C" {
     pub fn rt_scene_compile_info_ex(desc: *const RtSceneDesc, options: *const RtUploadOptions, out: *mut RtCompileInfo) -> c_int;
     pub fn rt_scene_compile_dump_ex(desc: *const RtSceneDesc, options: *const RtUploadOptions, nodes: *mut c_void, cap_nodes: u64,
                                     spheres: *mut f32, sphere_meta: *mut u32, cap_spheres: u64) -> c_int;
+    pub fn rt_scene_wide_layout_check(desc: *const RtSceneDesc, out: *mut RtWideInfo) -> c_int;
     pub fn rt_scene_top_layout_check(desc: *const RtSceneDesc, max_top: u32, out_n_top: *mut u64) -> c_int;
     pub fn rt_scene_compile_dump(desc: *const RtSceneDesc, nodes: *mut c_void, cap_nodes: u64, spheres: *mut f32,
                                  sphere_meta: *mut u32, cap_spheres: u64) -> c_int;

@@ -257,8 +257,9 @@ enum {
     RT_LAYOUT_NODES_32B = 64u,           /* scenes in HBM: 32-byte f32 records (with the top of the tree in LDS) instead of compressed ones */
     RT_LAYOUT_NO_SHADE_TABLES_IN_LDS = 128u,
     RT_LAYOUT_NO_EXTEND_TABLES_IN_LDS = 256u,
-    RT_LAYOUT_BINARY_NODES = 512u,       /* scenes in HBM: two-child compressed records instead of the 8-wide ones */
-    RT_LAYOUT_REFERENCE_COUNTERS = 1u | 4u | 16u | 512u
+    RT_LAYOUT_WIDE_NODES = 512u,         /* static BVH in HBM: walk an 8-wide tree, 8 lanes to a ray, one 128-byte node per visit (measured slower than
+                                            the default binary records on MI355X — VALU-bound at 8 rays per wave, DESIGN.md section 5 — kept as an option) */
+    RT_LAYOUT_REFERENCE_COUNTERS = 1u | 4u | 16u
 };
 typedef struct RtUploadOptions {
     uint32_t struct_bytes;     /* sizeof(RtUploadOptions) as the caller compiled it (the struct may grow at its end) */
@@ -382,6 +383,18 @@ int rt_runtime_libraries(char* out, uint64_t cap);
 /* Fault injection for the failure-path tests: the next `n` renders on this context fail with RT_ERR_DEVICE before any kernel is
    launched (n = 0 disarms). Lets a one-GPU box rehearse "one rank of a collective render fails". */
 int rt_test_fail_next_renders(RtCtx* ctx, uint32_t n);
+
+/* Builds the 8-wide tree a scene in HBM is walked through (a static BVH: spheres, rects, triangles, boxes under box nodes) and checks it
+   on the host: every primitive sits in exactly one leaf entry of at most eight members of one kind; every entry's box, decoded with the
+   device's own float arithmetic, contains everything below it; the depth fits the walk's stack. Fills `out`; RT_ERR_UNSUPPORTED when the
+   scene is not of that shape (it then keeps the binary walk). */
+typedef struct RtWideInfo {
+    uint64_t n_nodes, n_leaf_entries, n_inner_entries, n_prims;
+    uint32_t depth, _pad;
+    double mean_children;      /* used child slots per node (of 8) */
+    double mean_leaf_members;  /* primitives per leaf entry (of 8) */
+} RtWideInfo;
+int rt_scene_wide_layout_check(const RtSceneDesc* desc, RtWideInfo* out);
 
 const char* rt_last_error(const RtCtx* ctx);  /* ctx may be NULL: last error of this thread */
 uint32_t rt_abi_version(void);

@@ -18,8 +18,8 @@ RT_OUT_RGB_SUM_F32, RT_OUT_RGB8 = 0, 1
 RT_COMM_ID_BYTES = 128
 # RtUploadOptions.layout_flags
 (RT_LAYOUT_LISTS_AS_REFERENCE, RT_LAYOUT_LISTS_CULLED, RT_LAYOUT_NO_MEMBER_BOXES, RT_LAYOUT_MEMBER_BOXES, RT_LAYOUT_CHILD_ORDER_AS_REFERENCE,
- RT_LAYOUT_SCENE_IN_HBM, RT_LAYOUT_NODES_32B, RT_LAYOUT_NO_SHADE_TABLES_IN_LDS, RT_LAYOUT_NO_EXTEND_TABLES_IN_LDS, RT_LAYOUT_BINARY_NODES) = (1 << k for k in range(10))
-RT_LAYOUT_REFERENCE_COUNTERS = RT_LAYOUT_LISTS_AS_REFERENCE | RT_LAYOUT_NO_MEMBER_BOXES | RT_LAYOUT_CHILD_ORDER_AS_REFERENCE | RT_LAYOUT_BINARY_NODES
+ RT_LAYOUT_SCENE_IN_HBM, RT_LAYOUT_NODES_32B, RT_LAYOUT_NO_SHADE_TABLES_IN_LDS, RT_LAYOUT_NO_EXTEND_TABLES_IN_LDS, RT_LAYOUT_WIDE_NODES) = (1 << k for k in range(10))
+RT_LAYOUT_REFERENCE_COUNTERS = RT_LAYOUT_LISTS_AS_REFERENCE | RT_LAYOUT_NO_MEMBER_BOXES | RT_LAYOUT_CHILD_ORDER_AS_REFERENCE
 
 
 class RtVec3(C.Structure):
@@ -102,13 +102,18 @@ class RtUploadOptions(C.Structure):
                 ("leaf_collapse", C.c_uint32), ("list_park_cost", C.c_float)]
 
 
+class RtWideInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_leaf_entries", C.c_uint64), ("n_inner_entries", C.c_uint64), ("n_prims", C.c_uint64),
+                ("depth", C.c_uint32), ("_pad", C.c_uint32), ("mean_children", C.c_double), ("mean_leaf_members", C.c_double)]
+
+
 # every symbol include/rt_hip.h and include/rt_host.h declare
 RT_HIP_SYMBOLS = ["rt_ctx_create", "rt_ctx_destroy", "rt_scene_upload", "rt_scene_destroy", "rt_output_floats", "rt_render",
                   "rt_render_device", "rt_untile", "rt_resolve_device", "rt_last_error", "rt_abi_version", "rt_scene_compile_info",
                   "rt_scene_compile_dump", "rt_ctx_create_multi", "rt_ctx_destroy_multi", "rt_scene_upload_multi", "rt_scene_destroy_multi",
                   "rt_render_multi", "rt_render_multi_rgb8", "rt_last_error_multi", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_selftest",
                   "rt_render_gather", "rt_untile_rgb8", "rt_untile_device", "rt_scene_top_layout_check", "rt_scene_upload_ex", "rt_scene_upload_multi_ex",
-                  "rt_runtime_libraries", "rt_test_fail_next_renders", "rt_scene_compile_info_ex", "rt_scene_compile_dump_ex"]
+                  "rt_runtime_libraries", "rt_test_fail_next_renders", "rt_scene_compile_info_ex", "rt_scene_compile_dump_ex", "rt_scene_wide_layout_check"]
 RT_HOST_SYMBOLS = ["rt_host_scene_create", "rt_host_scene_desc", "rt_host_scene_camera", "rt_host_scene_destroy", "rt_host_camera_new",
                    "rt_host_write_color", "rt_host_tonemap", "rt_host_write_png"]
 
@@ -153,6 +158,8 @@ def declare(lib):
     lib.rt_scene_compile_info_ex.argtypes = [P(RtSceneDesc), P(RtUploadOptions), P(RtCompileInfo)]
     lib.rt_scene_compile_dump_ex.restype = i32
     lib.rt_scene_compile_dump_ex.argtypes = [P(RtSceneDesc), P(RtUploadOptions), vp, u64, P(C.c_float), P(u32), u64]
+    lib.rt_scene_wide_layout_check.restype = i32
+    lib.rt_scene_wide_layout_check.argtypes = [P(RtSceneDesc), P(RtWideInfo)]
     lib.rt_scene_compile_dump.restype = i32
     lib.rt_scene_compile_dump.argtypes = [P(RtSceneDesc), vp, u64, P(C.c_float), P(u32), u64]
     lib.rt_untile_rgb8.restype = i32

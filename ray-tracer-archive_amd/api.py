@@ -113,6 +113,13 @@ def compile_info(desc, layout_flags=0):
     return {n: getattr(info, n) for n, _ in info._fields_}
 
 
+def wide_layout_check(desc):
+    """rt_scene_wide_layout_check: builds and verifies the 8-wide tree of a static BVH on the host; returns its statistics."""
+    info = A.RtWideInfo()
+    _check(lib().rt_scene_wide_layout_check(C.byref(desc), C.byref(info)))
+    return {n: getattr(info, n) for n, _ in info._fields_ if not n.startswith("_")}
+
+
 def compile_dump(desc, layout_flags=0):
     """rt_scene_compile_dump[_ex]: (nodes structured array, spheres (n,4) f32, sphere_meta u32)."""
     info = compile_info(desc, layout_flags)

@@ -6,8 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librt_hip.so")
-SOURCES = ["csrc/kernels.hip", "csrc/rt_api.cpp", "csrc/rt_multi.cpp", "csrc/scene_compile.cpp", "host/host_capi.cpp"]
-HEADERS = ["csrc/kernels.h", "csrc/device_types.h", "csrc/rt_internal.hpp", "csrc/scene_compile.hpp", "host/rt_host.hpp", "../include/rt_hip.h", "../include/rt_host.h"]
+SOURCES = ["csrc/kernels.hip", "csrc/rt_api.cpp", "csrc/rt_multi.cpp", "csrc/scene_compile.cpp", "csrc/wide_bvh.cpp", "host/host_capi.cpp"]
+HEADERS = ["csrc/kernels.h", "csrc/device_types.h", "csrc/rt_internal.hpp", "csrc/scene_compile.hpp", "csrc/wide_bvh.hpp", "host/rt_host.hpp", "../include/rt_hip.h", "../include/rt_host.h"]
 # -ffp-contract=off: a float expression means the same IEEE operations wherever it is inlined, so a
 # sample's radiance does not depend on which kernel / call site generated its camera ray (and the
 # device evaluates the reference's expressions in the order written). Hot loops spell out fmaf/fma.
@@ -22,7 +22,7 @@ def source_hash():
     lay the scene out for them: what a PMC profile under profiles/ is valid for (bench.py refuses a profile taken from other sources)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ["csrc/kernels.hip", "csrc/kernels.h", "csrc/device_types.h", "csrc/scene_compile.cpp", "csrc/rt_api.cpp"]:
+    for f in ["csrc/kernels.hip", "csrc/kernels.h", "csrc/device_types.h", "csrc/scene_compile.cpp", "csrc/rt_api.cpp", "csrc/wide_bvh.cpp"]:
         h.update(open(os.path.join(HERE, f), "rb").read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()[:16]

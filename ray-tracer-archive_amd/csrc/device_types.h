@@ -56,6 +56,16 @@ static_assert(sizeof(NodeDev) == 32, "device node record is 32 bytes");
 // offset of the record to visit when the box is MISSED (passed: the next record). lo.x > hi.x marks a record without a box.
 struct Node16 { uint16_t lo[3], hi[3]; uint32_t link; };
 static_assert(sizeof(Node16) == 16, "compressed node record is 16 bytes");
+// 8-wide node of the walk from HBM (kernels.hip k_extend_wide; wide_bvh.cpp builds it): 128 bytes = one cache line = 8 chunks of 16 bytes,
+// chunk j for child j, fetched by the 8 lanes that share a ray with ONE load instruction:
+//   word 0  child: 0 = empty slot; bit 31 clear = index of the child's wide node + 1; bit 31 set = leaf payload (type | count <= 8 | first)
+//   word 1  qlo.x | qlo.y << 8 | qlo.z << 16 | qhi.x << 24     the child's box on the node's grid, 8 bits a plane, rounded outwards
+//   word 2  qhi.y | qhi.z << 8
+//   word 3  chunk 0..2: the grid's origin x, y, z (f32); chunk 3: the biased exponents of its power-of-two steps, ex | ey << 8 | ez << 16
+// plane = fma((float)q, 2^(e - 127), origin): the host replays this arithmetic when it picks the grid, so containment holds to the bit.
+constexpr uint32_t WIDE_NODE_BYTES = 128;
+constexpr uint32_t WIDE_MAX_DEPTH = 16;     // levels of the wide tree the walk's stack is sized for (one whole-node entry per level at worst); a deeper tree keeps the binary walk
+
 // payload words of the two shared self-loop records (leaf type 0 = no primitive work):
 constexpr uint32_t LEAF_IDLE = 1u << 24;   // the lane holds no ray
 constexpr uint32_t LEAF_DONE = 2u << 24;   // the lane's ray has visited every node

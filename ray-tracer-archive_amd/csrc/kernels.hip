@@ -1145,6 +1145,200 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_extend_wide — world.hit for scenes walked from HBM: 8 lanes per ray over an 8-wide BVH
+// ------------------------------------------------------------------------------------------------
+// The binary walk of a scene in HBM (k_extend M_C16) is bound by the CU's vector-memory pipe, not by bytes: every visit is a load of 16
+// bytes per lane from 64 different cache lines (TA 59 % busy, 45 % of the L1's cycles waiting for a fill, HBM at 15 % of its peak:
+// profiles/r02_pmc_c5*). Here a node is ONE 128-byte line holding eight children (device_types.h), and the eight lanes that share a ray
+// fetch it with one load instruction, 16 bytes each: a wave-load touches 8 lines instead of 64 and every byte of them is used. Lane j
+// decodes and tests child j; the group's hit mask comes out of a ballot, the nearest hit child out of three DPP min steps, and the walk
+// goes there first — near-first order for every ray without one record array per direction octant (96 MB for the million-sphere scene;
+// the 8-wide tree of the same scene is ~7 MB and mostly lives in L2). The other hit children go onto the group's stack in LDS, each lane
+// writing its own (child, t_near) in one ds_write; a popped entry whose t_near has fallen behind t_max meanwhile is dropped without a
+// fetch. (A first version kept ONE entry (node, pending mask) per level and fetched the node again for every further child: as many
+// line fetches as the binary walk made box tests.) Should a stack fill up, the rest of a node does wait as one (node, mask) entry.
+// A leaf entry holds up to eight primitives of one kind, tested side by side.
+// Same closest hit as the binary walk (a BVH only culls; the primitive tests are the same functions); among hits that tie within rounding
+// the winner can differ, as between the binary walk's record orders.
+DEVI uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false); }   // quad_perm [1,0,3,2]
+DEVI uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false); }   // quad_perm [2,3,0,1]
+DEVI uint32_t dpp_mirror8(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); }   // row_half_mirror: lane i <-> 7 - i of its 8
+DEVI uint32_t group_min(uint32_t v) { v = min(v, dpp_xor1(v)); v = min(v, dpp_xor2(v)); return min(v, dpp_mirror8(v)); }
+DEVI uint32_t group_max(uint32_t v) { v = max(v, dpp_xor1(v)); v = max(v, dpp_xor2(v)); return max(v, dpp_mirror8(v)); }
+template <int K> DEVI uint32_t group_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (K << 5) | 0x18); }   // value of lane K of the group
+DEVI uint32_t lane_value(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+
+#ifndef RT_WIDE_CHUNK
+#define RT_WIDE_CHUNK 128       // rays a wave takes from the queue per atomic (it holds 8 at a time)
+#endif
+#ifndef RT_WIDE_STACK
+#define RT_WIDE_STACK 24        // children a ray's stack takes one by one; beyond that a node waits as ONE entry (node, mask), at most one per level
+#endif
+constexpr uint32_t kWideStack = RT_WIDE_STACK, kWideStackAll = RT_WIDE_STACK + rtd::WIDE_MAX_DEPTH;   // 40 entries of 8 bytes: 10 KB per 256-thread group
+template <uint32_t FEAT, bool COUNT>
+__global__ void __launch_bounds__(256) k_extend_wide(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
+                                                     uint32_t* __restrict__ count_out_to_zero, unsigned long long* __restrict__ counters, RenderDev rd) {
+    __shared__ uint2 s_stack[(256 / 8) * kWideStackAll];
+    if (blockIdx.x == 0 && threadIdx.x < kQueues) count_out_to_zero[threadIdx.x * kQStride] = 0u;   // the next k_shade appends to them
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 7u, gbase = lane & 56u;
+    uint2* const stack = s_stack + (threadIdx.x >> 3) * kWideStackAll;          // this group's entries: x = child word, y = t_near bits; or x = node + 1, y = 0x80000000 | mask
+    const uint32_t wave_all = blockIdx.x * (blockDim.x >> 6) + first_lane_u32(threadIdx.x >> 6);
+    const uint32_t q = wave_all & (kQueues - 1u), qbase = q * rd.queue_cap, count = count_ptr[q * kQStride];
+    head += q * kQStride;
+    const uint32_t n_waves = max(1u, (gridDim.x * (blockDim.x >> 6)) / kQueues), wave_id = wave_all / kQueues;
+    constexpr uint32_t kC = RT_WIDE_CHUNK;
+    uint32_t chunk = count > kC * n_waves ? kC : max(8u, (count / (2u * n_waves)) & ~7u);
+    const uint32_t head0 = n_waves * chunk;          // the dynamic part of the queue starts behind the static first chunks
+    uint32_t w_next = min(wave_id * chunk, count), w_end = min(w_next + chunk, count);
+    bool exhausted = false;
+    const char* wide = reinterpret_cast<const char*>(sc.wide);
+
+    // the group's ray (the same values in its eight lanes) and its walk
+    bool active = false;
+    uint32_t slot = 0u, from = 0u, hit_prim = rtd::HIT_NONE;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0), oi = v3(0, 0, 0);
+    float a = 1.f, tmax = kInf;
+    uint32_t cur = 0u, mask = 0u, sp = 0u, leafw = 0u;       // cur = wide node index + 1 (0: pop), mask = its children still to look at
+    unsigned long long c_nodes = 0, c_prims[RT_N_PRIM_TYPES_K] = {0, 0, 0, 0, 0, 0};
+
+    for (;;) {
+        // ---- refill: groups without a ray take the next slots of the wave's chunk ----
+        {
+            const uint64_t need = __ballot(!active && j == 0u);
+            if (need != 0ull) {
+                if (!exhausted && w_next == w_end) {
+                    uint32_t start = 0;
+                    if (lane == 0u) start = atomicAdd(head, chunk);
+                    start = first_lane_u32(start) + head0;
+                    if (start >= count) exhausted = true;
+                    else {
+                        w_next = start; w_end = min(start + chunk, count);
+                        const uint32_t left = count - w_end;
+                        chunk = left > kC * n_waves ? kC : max(8u, (left / (2u * n_waves)) & ~7u);
+                    }
+                }
+                const uint32_t avail = w_end - w_next, take = min((uint32_t)__popcll(need), avail);
+                if (take != 0u) {
+                    const uint32_t rank = (uint32_t)__popcll(need & ((1ull << gbase) - 1ull));
+                    if (!active && rank < take) {
+                        slot = w_next + rank;
+                        const Float4 ro = pool.ray_o[qbase + slot], rdv = pool.ray_d[qbase + slot];     // the eight lanes read the same 32 bytes
+                        o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); from = __float_as_uint(rdv.w);
+                        const float kInvMax = 1e18f;                                                    // as set_slab_ray: a zero component stays finite
+                        inv = v3(fminf(fmaxf(fast_rcp(d.x), -kInvMax), kInvMax), fminf(fmaxf(fast_rcp(d.y), -kInvMax), kInvMax), fminf(fmaxf(fast_rcp(d.z), -kInvMax), kInvMax));
+                        oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+                        a = len2(d); tmax = kInf; hit_prim = rtd::HIT_NONE;
+                        cur = 1u; mask = 0xFFu; sp = 0u; leafw = 0u; active = true;
+                    }
+                    w_next += take;
+                }
+            }
+            if (__ballot(active) == 0ull) { if (exhausted) break; continue; }     // (nothing in flight and nothing taken: fetch the next chunk)
+        }
+        // ---- one node visit for every group that stands on a node (a group whose popped entry was dropped stands on none: it pops again below) ----
+        if (active && leafw == 0u && cur != 0u) {
+            const uint4 ch = *reinterpret_cast<const uint4*>(wide + (size_t)(cur - 1u) * rtd::WIDE_NODE_BYTES + j * 16u);
+            const float ox = __uint_as_float(group_lane<0>(ch.w)), oy = __uint_as_float(group_lane<1>(ch.w)), oz = __uint_as_float(group_lane<2>(ch.w));
+            const uint32_t ex = group_lane<3>(ch.w);
+            const float sx = __uint_as_float((ex & 0xFFu) << 23), sy = __uint_as_float(((ex >> 8) & 0xFFu) << 23), sz = __uint_as_float(((ex >> 16) & 0xFFu) << 23);
+            const float lx = fmaf((float)(ch.y & 0xFFu), sx, ox), ly = fmaf((float)((ch.y >> 8) & 0xFFu), sy, oy), lz = fmaf((float)((ch.y >> 16) & 0xFFu), sz, oz);
+            const float hx = fmaf((float)(ch.y >> 24), sx, ox), hy = fmaf((float)(ch.z & 0xFFu), sy, oy), hz = fmaf((float)((ch.z >> 8) & 0xFFu), sz, oz);
+            const float t0x = fmaf(lx, inv.x, -oi.x), t1x = fmaf(hx, inv.x, -oi.x);
+            const float t0y = fmaf(ly, inv.y, -oi.y), t1y = fmaf(hy, inv.y, -oi.y);
+            const float t0z = fmaf(lz, inv.z, -oi.z), t1z = fmaf(hz, inv.z, -oi.z);
+            const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), kTMin));
+            const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+            const bool valid = ch.x != 0u && ((mask >> j) & 1u) != 0u;
+            const bool boxhit = valid && tn <= tf;
+            if (COUNT) { const uint64_t vm = __ballot(valid); if (j == 0u) c_nodes += (unsigned long long)__popcll((vm >> gbase) & 0xFFull); }
+            const uint32_t hm = (uint32_t)(__ballot(boxhit) >> gbase) & 0xFFu;
+            if (hm != 0u) {
+                // the nearest hit child first; the others wait as one stack entry
+                const uint32_t kmin = group_min(boxhit ? ((__float_as_uint(tn) & ~7u) | j) : 0xFFFFFFFFu), jn = kmin & 7u;
+                const uint32_t rest = hm & ~(1u << jn), nrest = (uint32_t)__popc(rest);
+                if (nrest != 0u) {
+                    if (sp + nrest <= kWideStack) {
+                        if ((rest >> j) & 1u) stack[sp + (uint32_t)__popc(rest & ((1u << j) - 1u))] = make_uint2(ch.x, __float_as_uint(tn));
+                        sp += nrest;
+                    } else {                                                  // no room for them one by one: the node waits as a whole
+                        if (j == 0u) stack[sp] = make_uint2(cur, 0x80000000u | rest);
+                        ++sp;
+                    }
+                }
+                const uint32_t cw = lane_value(ch.x, gbase + jn);
+                if (cw >> 31) { leafw = cw; cur = 0u; } else { cur = cw; mask = 0xFFu; }
+            } else cur = 0u;
+        }
+        // ---- one leaf for every group that has reached one: its primitives side by side ----
+        if (active && leafw != 0u) {
+            const uint32_t type = (leafw >> 28) & 7u, cnt = (leafw >> 24) & 15u, first = leafw & rtd::LEAF_MAX_FIRST;
+            const bool mine = j < cnt;
+            float t = kInf; uint32_t id = 0u;
+            if (mine) {
+                const uint32_t idx = first + j;
+                if (type == rtd::LT_SPHERE) {
+                    const Float4 sp4 = sc.spheres[idx];
+                    id = (rtd::LT_SPHERE << 28) | idx;
+                    float tt;
+                    const int r = id == from ? 2 : sphere_fast(o, d, a, v3(sp4.x, sp4.y, sp4.z), sp4.w, kTMin, tmax, tt);
+                    bool h = r == 1;
+                    if (r == 2) h = (id == from) ? sphere_hit_from_surface(o, d, a, v3(sp4.x, sp4.y, sp4.z), sp4.w, kTMin, tmax, tt)
+                                                 : sphere_roots(o, d, a, v3(sp4.x, sp4.y, sp4.z), sp4.w, kTMin, tmax, tt);
+                    if (h) t = tt;
+                } else if ((FEAT & F_TRI) && type == rtd::LT_TRI) {
+                    const Float4 t0 = sc.tris[3 * idx], t1 = sc.tris[3 * idx + 1], t2 = sc.tris[3 * idx + 2];
+                    id = (rtd::LT_TRI << 28) | idx;
+                    float tt, bu, bv;
+                    if (id != from && tri_hit(o, d, f4xyz(t0), f4xyz(t1), f4xyz(t2), kTMin, tmax, tt, bu, bv)) t = tt;
+                } else if ((FEAT & F_RECT) && type == rtd::LT_RECT) {
+                    const Float4 r0 = sc.rects[2 * idx], r1 = sc.rects[2 * idx + 1];
+                    id = (rtd::LT_RECT << 28) | idx;
+                    float tt, ha, hb;
+                    if (id != from && rect_hit(o, d, r0, r1, kTMin, tmax, tt, ha, hb)) t = tt;
+                } else if ((FEAT & F_RECT) && type == rtd::LT_BOX) {
+                    const Float4 b0 = sc.boxes[2 * idx], b1 = sc.boxes[2 * idx + 1];
+                    const uint32_t id0 = (rtd::LT_RECT << 28) | __float_as_uint(b1.z);
+                    float tbox = tmax; uint32_t which;
+                    if (box_sides_hit(o, d, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, kTMin, tbox, from - id0, which)) { t = tbox; id = id0 + which; }
+                }
+            }
+            if (COUNT && j == 0u) c_prims[type == rtd::LT_SPHERE ? 0 : type == rtd::LT_TRI ? 3 : 2] += type == rtd::LT_BOX ? 6ull * cnt : (unsigned long long)cnt;
+            // the closest of them; on an exact tie the later member, as HittableList::hit's inclusive bounds give it (hittable_list.rs:39-51)
+            const uint32_t tb = group_min(__float_as_uint(t));
+            if (tb != __float_as_uint(kInf)) {
+                const uint32_t jw = group_max((mine && __float_as_uint(t) == tb) ? j + 1u : 0u) - 1u;
+                tmax = __uint_as_float(tb);
+                hit_prim = lane_value(id, gbase + jw);
+            }
+            leafw = 0u;
+        }
+        // ---- a group with nowhere to go takes its last stack entry, or is done ----
+        if (active && cur == 0u && leafw == 0u) {
+            if (sp == 0u) {
+                if (j == 0u) pool.hit[qbase + slot] = make_uint2(__float_as_uint(tmax), hit_prim);
+                active = false;
+            } else {
+                const uint2 e = stack[--sp];                                  // the same address in the group's eight lanes
+                if (e.y >> 31) { cur = e.x; mask = e.y & 0xFFu; }             // a node with children still to look at
+                else if (__uint_as_float(e.y) <= tmax) {                      // a child whose box was hit: still in front of the closest hit?
+                    if (e.x >> 31) leafw = e.x; else { cur = e.x; mask = 0xFFu; }
+                }                                                             // (else dropped: the next iteration pops again)
+            }
+        }
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) {
+            c_nodes += __shfl_down(c_nodes, off);
+            for (int k = 0; k < RT_N_PRIM_TYPES_K; ++k) c_prims[k] += __shfl_down(c_prims[k], off);
+        }
+        if (lane == 0u) {
+            atomicAdd(&counters[CTR_NODE_TESTS], c_nodes);
+            for (int k = 0; k < RT_N_PRIM_TYPES_K; ++k) if (c_prims[k]) atomicAdd(&counters[CTR_PRIM_TESTS + k], c_prims[k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // camera rays
 // ------------------------------------------------------------------------------------------------
 // One new sample: jitter (main.rs:752-753) then Camera::get_ray (camera.rs:60-70).
@@ -1807,10 +2001,34 @@ static uint32_t pick_variant(uint32_t need) {
     return F_ALL;
 }
 
+// the 8-lanes-per-ray walk: a persistent grid of 256-thread groups, every wave holding 8 rays at a time
+template <uint32_t FEAT, bool COUNT>
+static hipError_t launch_extend_wide_c(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
+                                       uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
+    static thread_local int per_cu = 0;
+    if (per_cu == 0) {
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_wide<FEAT, COUNT>, 256, 0);
+        if (e != hipSuccess) return e;
+        per_cu = std::max(per_cu, 1);
+    }
+    if (cfg.extend_geometry) { cfg.extend_geometry[0] = 256u; cfg.extend_geometry[1] = (uint32_t)per_cu; }
+    // a wave holds 8 rays: the resident set, or as many groups as the queue can feed (32 rays per 256-thread group at a time)
+    uint32_t groups = std::min<uint32_t>(cfg.n_cu * (uint32_t)per_cu, std::max<uint32_t>(1u, (cfg.max_rays + 31u) / 32u));
+    groups = (groups + 1u) / 2u * 2u;                              // 4 waves a group: a multiple of kQueues waves
+    hipLaunchKernelGGL((k_extend_wide<FEAT, COUNT>), dim3(groups), dim3(256), 0, stream, sc, pool, count_ptr, head, cz, counters, rd);
+    return hipGetLastError();
+}
+
 hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                          uint32_t* head, uint32_t* cz, unsigned long long* counters, bool count, hipStream_t stream) {
     if (cfg.max_rays == 0u) return hipSuccess;
     const uint32_t v = pick_variant(cfg.features);
+    if (sc.wide != nullptr) {
+        if (v == 0u) return count ? launch_extend_wide_c<0u, true>(cfg, sc, pool, rd, count_ptr, head, cz, counters, stream)
+                                  : launch_extend_wide_c<0u, false>(cfg, sc, pool, rd, count_ptr, head, cz, counters, stream);
+        return count ? launch_extend_wide_c<kVariantMesh, true>(cfg, sc, pool, rd, count_ptr, head, cz, counters, stream)
+                     : launch_extend_wide_c<kVariantMesh, false>(cfg, sc, pool, rd, count_ptr, head, cz, counters, stream);
+    }
 #define RT_EXT(M, F) launch_extend_t<M, F>(cfg, sc, pool, rd, count_ptr, head, cz, counters, count, stream)
 #define RT_EXT_V(M) (v == 0u ? RT_EXT(M, 0u) : v == kVariantMesh ? RT_EXT(M, kVariantMesh) : v == kVariantBox ? RT_EXT(M, kVariantBox) : RT_EXT(M, F_ALL))
     if (cfg.scene_in_lds) return RT_EXT_V(M_LDS);

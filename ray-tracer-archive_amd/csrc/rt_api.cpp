@@ -12,10 +12,12 @@
 #include <string>
 #include <limits>
 #include <memory>
+#include <functional>
 #include <vector>
 
 #include "rt_internal.hpp"
 #include "scene_compile.hpp"
+#include "wide_bvh.hpp"
 
 using namespace rti;
 
@@ -347,7 +349,7 @@ static size_t lds_scene_bytes(const rtc::CompiledScene& cs) {
 // scripts one-liners); no test and no host path sets them. A process that never sets them gets exactly what its RtUploadOptions say.
 struct rti::UploadOpts {
     rtc::CompileOptions compile;
-    bool lds_scene = true, node16 = true, octant_order = true, shade_lds = true, perlin_lds = true, extend_lds_tables = true, wide_nodes = true;
+    bool lds_scene = true, node16 = true, octant_order = true, shade_lds = true, perlin_lds = true, extend_lds_tables = true, wide_nodes = false;
     uint32_t max_top = 1024u, octant_axes = 0u /* 0 = pick; else 8 | mask */;
 };
 static rti::UploadOpts resolve_options(const RtUploadOptions* o) {
@@ -361,7 +363,7 @@ static rti::UploadOpts resolve_options(const RtUploadOptions* o) {
         u.node16 = !(f & RT_LAYOUT_NODES_32B);
         u.shade_lds = u.perlin_lds = !(f & RT_LAYOUT_NO_SHADE_TABLES_IN_LDS);
         u.extend_lds_tables = !(f & RT_LAYOUT_NO_EXTEND_TABLES_IN_LDS);
-        u.wide_nodes = !(f & RT_LAYOUT_BINARY_NODES);
+        u.wide_nodes = (f & RT_LAYOUT_WIDE_NODES) != 0u;
         if (o->struct_bytes >= 12u && o->lds_top_records) u.max_top = o->lds_top_records;
         if (o->struct_bytes >= 16u && o->octant_axes) u.octant_axes = 8u | (o->octant_axes & 7u);
         if (o->struct_bytes >= 20u) u.compile.leaf_collapse = o->leaf_collapse;
@@ -380,7 +382,7 @@ static rti::UploadOpts resolve_options(const RtUploadOptions* o) {
     if (const char* e = env("RT_SHADE_LDS")) u.shade_lds = u.shade_lds && e[0] != '0';
     if (const char* e = env("RT_SHADE_PERLIN_LDS")) u.perlin_lds = e[0] != '0';
     if (const char* e = env("RT_EXTEND_LDS_TABLES")) u.extend_lds_tables = u.extend_lds_tables && e[0] != '0';
-    if (const char* e = env("RT_WIDE_NODES")) u.wide_nodes = u.wide_nodes && e[0] != '0';
+    if (const char* e = env("RT_WIDE_NODES")) u.wide_nodes = e[0] != '0';
     u.max_top = std::min<uint32_t>(u.max_top, (128u * 1024u) / 32u);
     return u;
 }
@@ -396,6 +398,7 @@ struct rti::SceneImage {
     std::vector<unsigned char> blob, eblob;
     uint32_t sb[12] = {0}, perlin_only = 0u, eb[5] = {0}, eb_rect_stride = 32u;
     uint32_t features = 0u;
+    rtw::WideTree wide; bool use_wide = false;     // 8-wide nodes for k_extend_wide (a static BVH that does not fit LDS)
 };
 void rti::scene_image_free(SceneImage* im) { delete im; }
 
@@ -407,12 +410,22 @@ int rti::scene_image_build(const RtSceneDesc* desc, const RtUploadOptions* optio
     const int rc = rtc::compile_scene(*desc, opt.compile, cs);
     if (rc != RT_OK) { err = "scene: " + cs.error; return rc; }
     im->in_lds = opt.lds_scene && lds_scene_bytes(cs) <= kLdsSceneBudget;
+    im->features = scene_features(cs);
+    // RT_LAYOUT_WIDE_NODES: a static BVH in HBM (spheres / rects / triangles / boxes under box nodes only) walked 8 lanes to a ray over an
+    // 8-wide tree (kernels.hip k_extend_wide) instead of the binary records below.
+    if (!im->in_lds && opt.wide_nodes && opt.node16 && (im->features & ~(rtk::F_RECT | rtk::F_TRI)) == 0u && rtw::eligible(cs.nodes)) {
+        double extent = 0.0;
+        for (int a = 0; a < 3; ++a) extent = std::max(extent, std::max(std::fabs((double)cs.nodes[0].mn[a]), std::fabs((double)cs.nodes[0].mx[a])));
+        std::string werr;
+        im->use_wide = rtw::build(cs.nodes, (float)(6e-7 * extent), im->wide, werr) && im->wide.depth < rtd::WIDE_MAX_DEPTH;
+        if (!im->use_wide) im->wide = rtw::WideTree();
+    }
     // 16-byte compressed records for a scene that does not fit LDS (RT_LAYOUT_NODES_32B: 32-byte records with the top of the tree in LDS)
     im->c16 = !im->in_lds && opt.node16 && device_nodes16(cs.nodes, im->n16, im->grid_lo, im->grid_scale);
     // the record array once per direction octant (octant_order above), as long as 31-bit links reach; RT_LAYOUT_CHILD_ORDER_AS_REFERENCE: one
     // array, the reference's order (left, then right) — the order whose visit counts the tests compare with the CPU restatement's
     {
-        bool octants = im->c16 && opt.octant_order && 8ull * (cs.nodes.size() + 2) * 16ull < 0x7FFFFFF0ull;
+        bool octants = im->c16 && !im->use_wide && opt.octant_order && 8ull * (cs.nodes.size() + 2) * 16ull < 0x7FFFFFF0ull;   // (the wide walk orders near-first by itself)
         if (octants) {
             const uint32_t stride = (uint32_t)((cs.nodes.size() + 2) * 16);
             std::vector<rtd::Node16> all; all.reserve(8 * (cs.nodes.size() + 2));
@@ -482,7 +495,6 @@ int rti::scene_image_build(const RtSceneDesc* desc, const RtUploadOptions* optio
             eblob.clear();
         }
     }
-    im->features = scene_features(cs);
     *out = im.release();
     return RT_OK;
 }
@@ -500,6 +512,7 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->boxes, cs.boxes); up(s->media, cs.media);
     up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
     up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
+    if (im.use_wide) up(s->wide, im.wide.words);
     if (!im.blob.empty()) up(s->shade_blob, im.blob);
     if (!im.eblob.empty()) up(s->ext_blob, im.eblob);
     if (r == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = set_err(ctx, RT_ERR_DEVICE, "scene upload failed");   // the image is the caller's: its vectors outlive this wait
@@ -509,6 +522,7 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
     d.top_nodes = im.top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = im.top ? im.dn.n_top : 0u; d.n_records = im.c16 ? (uint32_t)im.n16.size() : im.dn.records();
     d.oct_stride = im.oct_stride; d.oct_mask = im.oct_mask;
+    d.wide = im.use_wide ? (const uint4*)s->wide.p : nullptr; d.n_wide = im.use_wide ? im.wide.n_nodes : 0u;
     d.nodes16 = im.c16 ? 1u : 0u; for (int a = 0; a < 3; ++a) { d.grid_lo[a] = im.grid_lo[a]; d.grid_scale[a] = im.grid_scale[a]; }
     d.n_prologue = (uint32_t)cs.prologue.size();
     for (uint32_t k = 0; k < rtd::MAX_PROLOGUE; ++k) d.prologue[k] = k < cs.prologue.size() ? cs.prologue[k] : 0u;
@@ -557,7 +571,7 @@ int rt_scene_destroy(RtCtx* ctx, RtScene* s) {
     if (!s) return RT_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     DevBuf* all[] = {&s->nodes, &s->spheres, &s->sphere_meta, &s->moving, &s->moving_meta, &s->rects, &s->rect_meta, &s->tris, &s->tri_meta, &s->boxes, &s->media,
-                     &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights, &s->top_nodes, &s->shade_blob, &s->ext_blob};
+                     &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights, &s->top_nodes, &s->shade_blob, &s->ext_blob, &s->wide};
     for (DevBuf* b : all) b->release();
     delete s;
     return RT_OK;
@@ -723,6 +737,9 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     // of the launch — and 2^21 was the best hand-over: 185.9 ms against 211.5 at 2^18.)
     uint32_t drain_at = prm->tail_paths ? prm->tail_paths : (1u << 18);          // RtParams.tail_paths (1 = never: a pool holds 8 queues of >= 1 path)
     if (const char* e = getenv("RT_DRAIN_AT")) drain_at = (uint32_t)std::strtoul(e, nullptr, 10);   // scripts/ only
+    // the 8-wide walk resolves hits that tie within rounding in its own way; handing a tail to the per-path kernel (binary records) would
+    // make such pixels depend on WHEN the hand-over happens, so a wide scene's wavefront loop runs to its end
+    if (scene->dev.wide != nullptr) drain_at = 0u;
     if (prm->flags & RT_FLAG_FUSED) drain_at = 0xFFFFFFFFu;
     uint32_t launched = 0, drained = 0;
     std::vector<uint32_t> iter_live;     // RT_DEBUG_ITER=1 (with RT_FLAG_TIMING): the host's bound of the largest queue at every iteration
@@ -897,6 +914,84 @@ int rt_scene_compile_dump_ex(const RtSceneDesc* desc, const RtUploadOptions* opt
     if (nodes) std::memcpy(nodes, cs.nodes.data(), cs.nodes.size() * sizeof(rtd::Node));
     if (spheres) std::memcpy(spheres, cs.spheres.data(), cs.spheres.size() * sizeof(rtd::Float4));
     if (sphere_meta) std::memcpy(sphere_meta, cs.sphere_meta.data(), cs.sphere_meta.size() * 4);
+    return RT_OK;
+}
+
+int rt_scene_wide_layout_check(const RtSceneDesc* desc, RtWideInfo* out) {
+    if (!desc || !out) return set_err(nullptr, RT_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    rtc::CompiledScene cs;
+    const int rc = rtc::compile_scene(*desc, cs);
+    if (rc != RT_OK) return set_err(nullptr, rc, "scene: " + cs.error);
+    if (!rtw::eligible(cs.nodes)) return set_err(nullptr, RT_ERR_UNSUPPORTED, "not a static BVH: the scene keeps the binary walk");
+    double extent = 0.0;
+    for (int a = 0; a < 3; ++a) extent = std::max(extent, std::max(std::fabs((double)cs.nodes[0].mn[a]), std::fabs((double)cs.nodes[0].mx[a])));
+    const float margin = (float)(6e-7 * extent);
+    rtw::WideTree wt; std::string err;
+    if (!rtw::build(cs.nodes, margin, wt, err)) return set_err(nullptr, RT_ERR_UNSUPPORTED, err);
+    // true box of one primitive (f64 from the compiled f32 data: what the kernel's tests see)
+    struct B { double mn[3], mx[3]; };
+    auto prim_box = [&](uint32_t type, uint32_t idx, B& b) {
+        auto set = [&](int a, double lo, double hi) { b.mn[a] = lo; b.mx[a] = hi; };
+        if (type == rtd::LT_SPHERE) { const rtd::Float4 s = cs.spheres[idx]; const double r = std::fabs((double)s.w); set(0, s.x - r, s.x + r); set(1, s.y - r, s.y + r); set(2, s.z - r, s.z + r); }
+        else if (type == rtd::LT_TRI) {
+            for (int a = 0; a < 3; ++a) { double lo = 1e300, hi = -1e300; for (int v = 0; v < 3; ++v) { const rtd::Float4 p = cs.tris[3 * idx + v]; const double c = a == 0 ? p.x : a == 1 ? p.y : p.z; lo = std::min(lo, c); hi = std::max(hi, c); } set(a, lo, hi); }
+        } else if (type == rtd::LT_RECT) {
+            const rtd::Float4 r0 = cs.rects[2 * idx], r1 = cs.rects[2 * idx + 1]; const int k = (int)r1.y, ia = k == 0 ? 1 : 0, ib = k == 2 ? 1 : 2;
+            set(k, r1.x, r1.x); set(ia, r0.x, r0.y); set(ib, r0.z, r0.w);
+        } else { const rtd::Float4 b0 = cs.boxes[2 * idx], b1 = cs.boxes[2 * idx + 1]; set(0, b0.x, b0.y); set(1, b0.z, b0.w); set(2, b1.x, b1.y); }
+    };
+    std::vector<uint8_t> seen[8];
+    seen[rtd::LT_SPHERE].assign(cs.sphere_meta.size(), 0); seen[rtd::LT_TRI].assign(cs.tri_meta.size(), 0);
+    seen[rtd::LT_RECT].assign(cs.rect_meta.size(), 0); seen[rtd::LT_BOX].assign(cs.boxes.size() / 2, 0);
+    std::string bad;
+    uint64_t used_slots = 0;
+    // content box of a wide node, bottom-up; every entry's decoded box must contain the content below it
+    std::vector<int> state(wt.n_nodes, 0);
+    std::function<bool(uint32_t, B&, uint32_t)> walk = [&](uint32_t w, B& content, uint32_t depth) -> bool {
+        if (w >= wt.n_nodes || state[w] != 0) { bad = "a wide node is referenced twice or out of range"; return false; }
+        state[w] = 1;
+        if (depth >= rtd::WIDE_MAX_DEPTH) { bad = "deeper than the walk's stack"; return false; }
+        const uint32_t* W = wt.words.data() + (size_t)w * 32u;
+        float org[3]; std::memcpy(&org[0], &W[3], 4); std::memcpy(&org[1], &W[7], 4); std::memcpy(&org[2], &W[11], 4);
+        float scl[3]; for (int a = 0; a < 3; ++a) { const uint32_t bits = ((W[15] >> (8 * a)) & 0xFFu) << 23; std::memcpy(&scl[a], &bits, 4); }
+        for (int a = 0; a < 3; ++a) { content.mn[a] = 1e300; content.mx[a] = -1e300; }
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t* c = W + 4 * k;
+            if (c[0] == 0u) continue;
+            ++used_slots;
+            const uint32_t q[6] = {c[1] & 0xFFu, (c[1] >> 8) & 0xFFu, (c[1] >> 16) & 0xFFu, c[1] >> 24, c[2] & 0xFFu, (c[2] >> 8) & 0xFFu};
+            B below;
+            if (c[0] >> 31) {
+                const uint32_t type = (c[0] >> 28) & 7u, cnt = (c[0] >> 24) & 15u, first = c[0] & rtd::LEAF_MAX_FIRST;
+                if (cnt == 0u || cnt > 8u || seen[type].empty()) { bad = "leaf entry with a bad kind or count"; return false; }
+                for (int a = 0; a < 3; ++a) { below.mn[a] = 1e300; below.mx[a] = -1e300; }
+                for (uint32_t m = 0; m < cnt; ++m) {
+                    if (first + m >= seen[type].size() || seen[type][first + m]++) { bad = "a primitive is in two leaf entries or out of range"; return false; }
+                    B pb; prim_box(type, first + m, pb);
+                    for (int a = 0; a < 3; ++a) { below.mn[a] = std::min(below.mn[a], pb.mn[a]); below.mx[a] = std::max(below.mx[a], pb.mx[a]); }
+                }
+                out->n_prims += cnt;
+            } else if (!walk(c[0] - 1u, below, depth + 1)) return false;
+            for (int a = 0; a < 3; ++a) {
+                const double lo = (double)std::fmaf((float)q[a], scl[a], org[a]), hi = (double)std::fmaf((float)q[3 + a], scl[a], org[a]);
+                if (!(lo <= below.mn[a] - margin && hi >= below.mx[a] + margin)) { bad = "an entry's decoded box does not contain what is below it"; return false; }
+                content.mn[a] = std::min(content.mn[a], below.mn[a]); content.mx[a] = std::max(content.mx[a], below.mx[a]);
+            }
+        }
+        return true;
+    };
+    B all;
+    if (!walk(0u, all, 0u)) return set_err(nullptr, RT_ERR_DEVICE, "wide tree: " + bad);
+    for (uint32_t t : {(uint32_t)rtd::LT_SPHERE, (uint32_t)rtd::LT_TRI, (uint32_t)rtd::LT_RECT, (uint32_t)rtd::LT_BOX})
+        for (size_t i = 0; i < seen[t].size(); ++i) {
+            // (spheres that only bound a medium, and the rects that are a Box's sides, are not in any leaf: a static BVH has no media, and box sides are reached through their Box)
+            if (seen[t][i] == 0 && !(t == rtd::LT_RECT && !cs.boxes.empty())) return set_err(nullptr, RT_ERR_DEVICE, "wide tree: a primitive is in no leaf entry");
+        }
+    for (uint32_t w = 0; w < wt.n_nodes; ++w) if (!state[w]) return set_err(nullptr, RT_ERR_DEVICE, "wide tree: an unreachable node");
+    out->n_nodes = wt.n_nodes; out->n_leaf_entries = wt.n_leaf_entries; out->n_inner_entries = wt.n_inner_entries; out->depth = wt.depth;
+    out->mean_children = wt.n_nodes ? (double)used_slots / wt.n_nodes : 0.0;
+    out->mean_leaf_members = wt.n_leaf_entries ? (double)out->n_prims / wt.n_leaf_entries : 0.0;
     return RT_OK;
 }
 

@@ -49,7 +49,7 @@ struct RtCtx {
 
 struct RtScene {
     rti::DevBuf nodes, spheres, sphere_meta, moving, moving_meta, rects, rect_meta, tris, tri_meta, boxes, media, xforms, wraps, mat_a, mat_b, textures, perlins, images,
-        image_bytes, lights, top_nodes, shade_blob, ext_blob;
+        image_bytes, lights, top_nodes, shade_blob, ext_blob, wide;
     rtk::SceneDev dev{};
     uint32_t features = 0; bool in_lds = false;
     int bg_mode = 0; float bg[3] = {0, 0, 0};

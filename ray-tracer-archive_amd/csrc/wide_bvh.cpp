@@ -29,7 +29,21 @@ struct Builder {
     static uint32_t ltype(uint32_t leaf) { return leaf >> 28; }
     static uint32_t lcount(uint32_t leaf) { return (leaf >> 24) & 15u; }
     static uint32_t lfirst(uint32_t leaf) { return leaf & rtd::LEAF_MAX_FIRST; }
-    Box box_of(size_t i) const { Box b; for (int a = 0; a < 3; ++a) { b.mn[a] = nodes[i].mn[a]; b.mx[a] = nodes[i].mx[a]; } return b; }
+    // a leaf record without a box of its own (the two unlike members of a span-2 node, bvh.rs:99-107) counts with its parent's box
+    std::vector<Box> eff;
+    void effective_boxes() {
+        eff.resize(n);
+        std::vector<std::pair<size_t, Box>> open;        // enclosing boxed subtrees: (end, box)
+        for (size_t i = 0; i < n; ++i) {
+            while (!open.empty() && open.back().first <= i) open.pop_back();
+            Box b;
+            if (std::isfinite(nodes[i].mn[0])) { for (int a = 0; a < 3; ++a) { b.mn[a] = nodes[i].mn[a]; b.mx[a] = nodes[i].mx[a]; } }
+            else b = open.back().second;                 // eligible() guarantees there is one
+            eff[i] = b;
+            if (std::isfinite(nodes[i].mn[0]) && sub_end(i) > i + 1) open.push_back({sub_end(i), b});
+        }
+    }
+    Box box_of(size_t i) const { return eff[i]; }
 
     // primitives of the subtree at i as one contiguous run of one kind, if they are one
     void find_runs() {
@@ -62,18 +76,25 @@ struct Builder {
             for (size_t c = p + 1; c < sub_end(p); c = sub_end(c)) into.push_back(c);
         };
         kids_of(i, kids);
-        for (;;) {
+        // first the children that cannot be a leaf entry (more than 8 primitives, or of two kinds), largest surface first; then, while slots
+        // are still free, leaf entries of more than kSplitAbove members: the box tests of a node's eight slots cost one visit however many
+        // are used, and two boxes around 3 + 4 primitives cull better than one around 7 — but a leaf visit keeps as many lanes busy as it has
+        // members, so small entries stay whole
+        constexpr uint32_t kSplitAbove = 4;
+        for (int pass = 0; pass < 2;) {
             if (kids.size() >= 8) break;
             int best = -1; double area = -1.0;
             for (size_t k = 0; k < kids.size(); ++k) {
                 const size_t c = kids[k];
-                if (is_leaf_entry(c) || nodes[c].leaf != 0u) continue;
+                if (nodes[c].leaf != 0u) continue;
+                const bool leafable = is_leaf_entry(c);
+                if (pass == 0 ? leafable : !(leafable && run[c].count > kSplitAbove)) continue;
                 std::vector<size_t> g; kids_of(c, g);
                 if (g.empty() || kids.size() - 1 + g.size() > 8) continue;
                 const double a = half_area(box_of(c));
                 if (a > area) { area = a; best = (int)k; }
             }
-            if (best < 0) break;
+            if (best < 0) { ++pass; continue; }
             std::vector<size_t> g; kids_of(kids[(size_t)best], g);
             kids.erase(kids.begin() + best);
             kids.insert(kids.end(), g.begin(), g.end());
@@ -128,16 +149,21 @@ struct Builder {
         if (es.empty()) return;
         float mn[3], mx[3];
         for (int a = 0; a < 3; ++a) { mn[a] = std::numeric_limits<float>::infinity(); mx[a] = -mn[a]; }
-        for (const Entry& e : es) for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], e.box.mn[a] - margin); mx[a] = std::max(mx[a], e.box.mx[a] + margin); }
+        for (const Entry& e : es) for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(mn[a], std::nextafterf(e.box.mn[a] - margin, -std::numeric_limits<float>::infinity()));
+            mx[a] = std::max(mx[a], std::nextafterf(e.box.mx[a] + margin, std::numeric_limits<float>::infinity()));
+        }
         float org[3], scl[3]; uint32_t ebyte[3];
         for (int a = 0; a < 3; ++a) {
-            // grid: step 2^e, origin one step below the lowest plane; coarser until every child's planes decode (in the device's float
-            // arithmetic) to a box that contains the child's own, margin included, inside 0..255
+            // grid: step 2^e, origin two steps below the lowest plane (one for the outward step of the lowest child, one for the float
+            // rounding of the origin itself); coarser until every child's planes decode (in the device's float arithmetic) to a box that
+            // contains the child's own, margin included, inside 0..255 — which the first candidate does unless coordinates dwarf the node
             int e = (int)std::ceil(std::log2(std::max((double)mx[a] - (double)mn[a], 1e-30) / 250.0));
             e = std::max(-100, std::min(100, e));
             for (;; ++e) {
                 const float s = std::ldexp(1.0f, e);
-                float o = mn[a] - s; if ((double)o > (double)mn[a] - (double)s) o = std::nextafterf(o, -std::numeric_limits<float>::infinity());
+                const double od = (double)mn[a] - 2.0 * (double)s;
+                float o = (float)od; if ((double)o > od) o = std::nextafterf(o, -std::numeric_limits<float>::infinity());
                 bool ok = true;
                 for (const Entry& en : es) {
                     const double lo = (double)en.box.mn[a] - margin, hi = (double)en.box.mx[a] + margin;
@@ -172,8 +198,11 @@ struct Builder {
 
 bool eligible(const std::vector<rtd::Node>& nodes) {
     if (nodes.empty()) return false;
-    for (const rtd::Node& nd : nodes) {
-        for (int a = 0; a < 3; ++a) if (!std::isfinite(nd.mn[a]) || !std::isfinite(nd.mx[a])) return false;
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const rtd::Node& nd = nodes[i];
+        bool boxed = true;
+        for (int a = 0; a < 3; ++a) if (!std::isfinite(nd.mn[a]) || !std::isfinite(nd.mx[a])) boxed = false;
+        if (!boxed && (i == 0 || nd.leaf == 0u)) return false;     // only a LEAF may lack a box (it counts with its parent's), never the root
         if (nd.leaf != 0u) {
             const uint32_t t = nd.leaf >> 28;
             if (!(t == rtd::LT_SPHERE || t == rtd::LT_RECT || t == rtd::LT_TRI || t == rtd::LT_BOX)) return false;
@@ -187,6 +216,7 @@ bool build(const std::vector<rtd::Node>& nodes, float margin, WideTree& out, std
     out = WideTree();
     if (!eligible(nodes)) { err = "not a static BVH"; return false; }
     Builder b(nodes, margin, out);
+    b.effective_boxes();
     b.find_runs();
     if (b.run[0].ok && b.run[0].count > 8u && nodes[0].leaf != 0u) b.make_run_node(b.box_of(0), b.run[0], 0);
     else b.make_wide(0, 0);

@@ -8,7 +8,7 @@ P=ray-tracer-archive_amd
 mkdir -p $P/lib/variants oracle/_build
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
 g++ -std=c++17 -fPIC -shared $SAN -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Wno-deprecated-declarations -Wno-unused-result \
-    -o $P/lib/variants/librt_hip_asan.so $P/csrc/rt_api.cpp $P/csrc/rt_multi.cpp $P/csrc/scene_compile.cpp $P/host/host_capi.cpp scripts/asan_host_stubs.cpp \
+    -o $P/lib/variants/librt_hip_asan.so $P/csrc/rt_api.cpp $P/csrc/rt_multi.cpp $P/csrc/scene_compile.cpp $P/csrc/wide_bvh.cpp $P/host/host_capi.cpp scripts/asan_host_stubs.cpp \
     -L/opt/rocm/lib -lamdhip64 -lz -ldl -Wl,-rpath,/opt/rocm/lib
 g++ -std=c++17 -fPIC -shared $SAN -pthread -o oracle/_build/liboracle_asan.so oracle/oracle.cpp
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1

@@ -85,7 +85,7 @@ def test_rust_shim_covers_the_header():
     bound = sorted(set(re.findall(r"pub fn (rt_[a-z0-9_]+)\s*\(", rs)))
     assert bound == declared_functions("rt_hip.h")
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rt_hip.h")).read(), flags=re.S)
-    for name in ["RtVec3", "RtCamera", "RtTexture", "RtPerlin", "RtImage", "RtMaterial", "RtHittable", "RtSceneDesc", "RtParams", "RtStats", "RtCompileInfo", "RtUploadOptions"]:
+    for name in ["RtVec3", "RtCamera", "RtTexture", "RtPerlin", "RtImage", "RtMaterial", "RtHittable", "RtSceneDesc", "RtParams", "RtStats", "RtCompileInfo", "RtUploadOptions", "RtWideInfo"]:
         body_c = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr, flags=re.S).group(1)
         fields_c = []
         for decl in body_c.split(";"):

@@ -258,3 +258,28 @@ def test_top_of_tree_layout(pkg):
         hs = pkg.HostScene(name, 1)
         for k in (3, 50, 400):
             check(hs.desc, k)
+
+
+def test_wide_tree_of_a_static_bvh(pkg, tmp_path):
+    """The 8-wide tree scenes in HBM are walked through (csrc/wide_bvh.cpp), built and checked on the host: every primitive in exactly one
+    leaf entry of <= 8 members of one kind, every entry's box — decoded with the device's float arithmetic — containing what is below it,
+    depth within the walk's stack. Reference-shaped and SAH binary trees, spheres + triangles + a ground rect; scenes with lists, wrappers,
+    media or moving spheres are not of that shape and keep the binary walk."""
+    import crops as K
+    obj = tmp_path / "t.obj"
+    K.write_torus_obj(str(obj), 64, 32)                        # 4096 triangles
+    for name in ("big_obj:", "big_obj_sah:"):
+        hs = pkg.HostScene(name + str(obj), 5, 20000)
+        w = pkg.wide_layout_check(hs.desc)
+        assert w["n_prims"] == 20000 + 4096 + 1 and w["depth"] < 16
+        assert w["mean_children"] > 5.0 and w["mean_leaf_members"] > 1.5, w
+        print(name, w)
+        assert w["n_nodes"] * 128 < 0.5 * (20000 + 4096) * 2 * 16 * 4          # smaller than the four binary record orders it replaces
+    hs = pkg.HostScene("book1", 1)
+    w = pkg.wide_layout_check(hs.desc)
+    assert w["n_prims"] == 484
+    for name in ("cornell", "cornell_smoke", "book1_ref"):
+        hs = pkg.HostScene(name, 1)                      # (kept alive: its desc points into it)
+        with pytest.raises(pkg.RtError) as e:
+            pkg.wide_layout_check(hs.desc)
+        assert e.value.code == pkg._abi.RT_ERR_UNSUPPORTED

@@ -203,6 +203,18 @@ def test_config5_million_spheres_and_mesh(pkg, orc, gpu):
     img3, st3 = gpu.render(one_order, cam, prm)
     assert (np.abs(img - img3).max(axis=2) > 0).mean() < 2e-3 and abs(st3["segments"] - st["segments"]) <= 1e-4 * st["segments"]
     assert st["node_tests"] < 0.85 * st3["node_tests"] and sum(st["prim_tests"][:5]) < 0.85 * sum(st3["prim_tests"][:5])
+    # the 8-wide tree walked 8 lanes to a ray (RT_LAYOUT_WIDE_NODES, kernels.hip k_extend_wide: one 128-byte node per visit, nearest child
+    # first, the other hit children on a stack in LDS): the same picture up to such ties, on the SAH tree and on the reference-shaped one,
+    # far fewer node visits (each counts the child boxes it tests: <= 8); a tile rendered alone equals the full frame bit for bit
+    for h, base in ((hs, img), (ref_scene, img2)):
+        wide = gpu.upload(h.desc, pkg._abi.RT_LAYOUT_WIDE_NODES)
+        img4, st4 = gpu.render(wide, cam, prm)
+        assert (np.abs(base - img4).max(axis=2) > 0).mean() < 2e-3 and abs(st4["segments"] - st["segments"]) <= 2e-4 * st["segments"]
+        assert st4["node_tests"] < 8 * 0.5 * st3["node_tests"]          # fewer than half as many visits as the one-order binary walk makes box tests
+        tile, _ = gpu.render(wide, cam, pkg.make_params(W, H, 16, tile_size=32, shard_index=4, shard_count=9))
+        assert np.array_equal(tile.reshape(32, 32, 3), img4[32:64, 32:64])
+        again, _ = gpu.render(wide, cam, pkg.make_params(W, H, 16, pool_slots=8192))
+        assert np.array_equal(again, img4)                                # independent of the pool size (no hand-over to the per-path kernel)
 
 
 def test_imported_obj_mesh(pkg, orc, gpu, tmp_path):
