@@ -24,7 +24,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 78.64: 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions per second (= 157.3 TFLOP/s FP32 FMA / 2)
 NODE_BYTES, SPHERE_BYTES, RAY_BYTES, HIT_BYTES = 32, 20, 32, 8   # SURVEY.md §8(d) record sizes
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_book1.json")
+LDS_PEAK_GCYC = 256 * 2.4                          # 614.4: 256 CUs x 2.4 GHz LDS-array cycles per second, in 1e9 (one 256-byte-wide access slot per CU and cycle)
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_book1.json")
+PMC_PROFILE_C5 = os.path.join("profiles", "r03_pmc_c5.json")
 
 
 def host_cores():
@@ -61,13 +63,24 @@ def other_configs(pkg, ctx, A, B, dev, stream):
     import torch
     res = {}
     cases = [("C3_book2_final_800x800", "final", 800, 800, 100), ("C4_cornell_600x600", "cornell", 600, 600, 250),
-             ("C5_standin_1M_spheres_262K_triangles_2048x2048", "big_sah", 2048, 2048, 16)]
+             ("C5_standin_1M_spheres_262K_triangles_2048x2048", "big_sah", 2048, 2048, 16),
+             # the scene the C5 PARITY crops are taken from (tests/crops.py): 1 M spheres + the 131 072-triangle torus imported from an OBJ file,
+             # reference-shaped tree, 4096x4096 — timed beside the stand-in that is profiled
+             ("C5_parity_scene_1M_spheres_obj_mesh_4096x4096", "big_obj", 4096, 4096, 4)]
     for tag, name, W, H, spp in cases:
         if name == "final":
             from PIL import Image
             hs = pkg.HostScene("final", 1, image=np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "earthmap_rgb.png")).convert("RGB")))
         elif name == "big_sah":
             hs = pkg.HostScene("big_sah", 5, 1000000, 512)
+        elif name == "big_obj":
+            import tempfile
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import crops as K
+            obj = os.path.join(tempfile.gettempdir(), "bench_torus_512x128.obj")
+            if not os.path.exists(obj):
+                K.write_torus_obj(obj, 512, 128)
+            hs = pkg.HostScene("big_obj:" + obj, 5, 1000000)
         else:
             hs = pkg.HostScene(name, 0)
         t0 = time.perf_counter()
@@ -87,16 +100,17 @@ def other_configs(pkg, ctx, A, B, dev, stream):
              "k_shade_ms": round(st["shade_ms"], 2), "segments": st["segments"], "bvh_in_lds": st["bvh_in_lds"], "scene_upload_s": round(up, 2)}
         if name == "big_sah":
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_c5.json")))
+                tj = json.load(open(os.path.join(ROOT, PMC_PROFILE_C5)))
                 if tj.get("source_hash") == B.source_hash() and st["extend_ms"] > 0:
+                    # the profile's bytes and this run's segments both cover the wavefront launches AND the launch that carries the tail
                     bps = tj["kernels"]["k_extend"]["bytes_per_segment"]
-                    gbs = bps * st["segments"] / (st["extend_ms"] * 1e-3) / 1e9
+                    gbs = bps * st["segments"] / ((st["extend_ms"] + st["drain_ms"]) * 1e-3) / 1e9
                     r["k_extend_hbm"] = {"bound": "hbm", "bytes_per_segment": bps, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                          "l2_hit_rate": tj["kernels"]["k_extend"].get("l2_hit_rate"),
-                                         "note": "PMC FETCH_SIZE x 2 + WRITE_SIZE per segment (profiles/r02_pmc_c5.json) x this run's segments / k_extend time; the walk is "
+                                         "note": f"PMC FETCH_SIZE x 2 + WRITE_SIZE per segment ({PMC_PROFILE_C5}) x this run's segments / (k_extend + tail launch) time; the walk is "
                                                  "bound by the CU's L1 under divergent 16-byte loads, not by HBM bytes (DESIGN.md section 5)"}
                 else:
-                    r["k_extend_hbm"] = {"note": "profiles/r02_pmc_c5.json was measured on other sources: not used"}
+                    r["k_extend_hbm"] = {"note": f"{PMC_PROFILE_C5} was measured on other sources: not used"}
             except Exception as e:
                 r["k_extend_hbm"] = {"error": repr(e)}
         res[tag] = r
@@ -304,14 +318,23 @@ def main():
                 pmc = tj["kernels"]["k_extend"]
         except Exception as e:
             pmc_note = f"{PMC_PROFILE}: {e!r}"
-        roof = {"bound": "valu", "kernel": "k_extend", "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s",
-                "peak_note": "256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz VALU lane-instructions/s (FP32 FMA peak 157.3 TFLOP/s = 2 flop per lane-instruction)",
+        roof = {"bound": "lds", "kernel": "k_extend",
                 "avg_launch_ms": round(ext_ms / max(1, launches), 4), "launches": launches, "segments_per_launch": round(seg / max(1, launches), 1),
                 "node_tests_per_segment": round(vn, 2), "sphere_tests_per_segment": round(vp, 2), "segments_per_sample": round(seg_per_sample, 3)}
         if pmc is not None and ext_s > 0:
+            # The scene is LDS-resident and every node visit is two 16-byte LDS gathers per lane: of the CU's units the LDS array is the
+            # busiest (PMC), so it is the roof this kernel is priced against; VALU lanes are printed beside it. Both are cycles (or
+            # lane-instructions) per SEGMENT from the committed PMC pass of this workload x this run's segments / the live launch time.
             lops = pmc["valu_lane_instructions_per_segment"]
-            achieved = seg * lops / ext_s / 1e12
-            roof.update({"achieved": round(achieved, 2), "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
+            valu = seg * lops / ext_s / 1e12
+            lds_cyc = pmc["counters"]["SQ_LDS_IDX_ACTIVE"] / tj["segments"]
+            lds = seg * lds_cyc / ext_s / 1e9
+            roof.update({"peak": round(LDS_PEAK_GCYC, 1), "unit": "G LDS-array cycles/s",
+                         "peak_note": "256 CUs x 2.4 GHz: one LDS-array cycle (a 256-byte-wide access slot) per CU and clock; SQ_LDS_IDX_ACTIVE counts the "
+                                      "cycles the array works, bank conflicts included (MI355X_MICROARCH.md, LDS)",
+                         "achieved": round(lds, 1), "frac": round(lds / LDS_PEAK_GCYC, 4), "lds_array_cycles_per_segment": round(lds_cyc, 1),
+                         "valu": {"bound": "valu", "achieved": round(valu, 2), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlaneop/s", "frac": round(valu / VALU_PEAK_TLANEOPS, 4),
+                                  "peak_note": "256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz VALU lane-instructions/s (FP32 FMA peak 157.3 TFLOP/s = 2 flop per lane-instruction)"},
                          "lane_instructions_per_segment": lops, "lane_instructions_per_launch": round(lops * seg / max(1, launches)),
                          "traffic": round(pmc["bytes_per_segment"] * seg / max(1, launches) / 1e6, 3), "traffic_unit": "MB/launch",
                          "traffic_source": f"{pmc['bytes_per_segment']} B/segment HBM (PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes) x segments_per_launch",
@@ -328,7 +351,7 @@ def main():
                             "measured_hbm_bytes_per_segment": pmc["bytes_per_segment"] if pmc else None,
                             "measured_hbm_gbs": round(seg * pmc["bytes_per_segment"] / ext_s / 1e9, 1) if pmc and ext_s > 0 else None,
                             "measured_over_hbm_peak": round(seg * pmc["bytes_per_segment"] / ext_s / 1e9 / HBM_PEAK_GBS, 4) if pmc and ext_s > 0 else None,
-                            "note": "the 24 KB scene is LDS-resident: HBM sees the ray records only; the HBM roofline applies to config 5 (profiles/r02_pmc_c5.json)"}
+                            "note": f"the 24 KB scene is LDS-resident: HBM sees the ray records only; the HBM roofline applies to config 5 ({PMC_PROFILE_C5})"}
         # the second kernel of a step, k_shade, is the HBM-side one: PMC bytes per segment x this run's segments / its kernel time
         if pmc is not None and shade_ms > 0 and "k_shade" in tj["kernels"]:
             sb = tj["kernels"]["k_shade"]["bytes_per_segment"]
@@ -337,11 +360,27 @@ def main():
                                "share_of_step": round(shade_ms / max(1e-9, ext_ms + shade_ms + other_ms), 3)}
         out["roofline"] = roof
     except Exception as e:   # the contract line must survive a failure in the extras
-        out["roofline"] = {"bound": "valu", "error": repr(e)}
+        out["roofline"] = {"bound": "lds", "error": repr(e)}
 
     variants = {}
     if strong is not None:
         variants["strong_4096"] = strong
+    # ---- the metric as SURVEY 8(d) words it: rt_render (framebuffer resident on the HOST when the call returns), 3 warm + 5 timed, median ----
+    if n_gpus == 1 and not args.no_variants:
+        try:
+            import numpy as np
+            hprm = pkg.make_params(W, H, args.spp, max_depth=50, seed=1)
+            for _ in range(3):
+                ctx.render(scene, cam, hprm)
+            ts = []
+            for _ in range(5):
+                t1 = time.perf_counter(); ctx.render(scene, cam, hprm); ts.append(time.perf_counter() - t1)
+            med = float(np.median(ts))
+            variants["host_resident_median"] = {"value": round(W * H * args.spp / med / 1e6, 1), "unit": "Msamples/s", "ms": round(med * 1e3, 2), "runs_ms": [round(t * 1e3, 2) for t in ts],
+                                                "note": "rt_render: first launch to framebuffer in host memory (one 11.5 MB D2H copy + the numpy buffer the binding allocates), "
+                                                        "3 warm + 5 timed, median (SURVEY 8(d)); `value` above is the bench contract's mean with the frame left in HBM"}
+        except Exception as e:
+            variants["host_resident_median"] = {"error": repr(e)}
     # ---- same workload on the RT_BVH_SAH tree (library option, not the reference's builder): reported beside, never as `value` ----
     if n_gpus == 1 and not args.no_variants:
         try:

@@ -25,6 +25,7 @@ struct SceneDev {
     float grid_lo[3], grid_scale[3];
     uint32_t oct_mask;       // direction signs that select an array (x = 1, y = 2, z = 4)
     uint32_t oct_stride;     // M_C16: bytes between the record arrays of two direction octants (rt_api.cpp octant_order); 0 = one array
+    uint32_t sort_rays;      // 1: k_shade orders the survivors of a workgroup by (octant, origin cell) before it writes them (scenes walked from HBM)
     const uint4* wide; uint32_t n_wide;   // 8-wide nodes (device_types.h), nullptr: the scene is walked through its binary records
     uint32_t n_prologue, prologue[rtd::MAX_PROLOGUE];   // moving spheres / media every ray meets: tested when a walk begins
     uint32_t n_prim_kinds;   // how many of {sphere, moving sphere, rect, triangle, medium} the scene holds

@@ -1397,6 +1397,37 @@ DEVI uint32_t block_alloc(bool flag, uint32_t* counter, uint32_t* s_scan) {
     return flag ? base + prefix + lane_rank(m) : 0xFFFFFFFFu;
 }
 
+// The same allocation, but the workgroup's survivors leave it ORDERED by `key` (< kSortBins; counting sort in LDS): paths of one key get
+// consecutive slots, keys in ascending order. For scenes walked from HBM the key is (direction octant, cell of the origin): the 64 rays
+// a wave of k_extend then takes together start in the same record array and near each other, so their first visits hit the same cache
+// lines (the walk is bound by the CU's L1 under divergent 16-byte loads). Which path of a key gets which slot
+// depends on the order the LDS atomics land in; the picture does not (per-item sums, RNG keyed by pixel and sample).
+constexpr uint32_t kSortBins = 512;
+DEVI uint32_t block_alloc_sorted(bool flag, uint32_t key, uint32_t* counter, uint32_t* s_bins /* kSortBins + 2 */) {
+    for (uint32_t b = threadIdx.x; b < kSortBins + 2u; b += blockDim.x) s_bins[b] = 0u;
+    __syncthreads();
+    uint32_t rank = 0u;
+    if (flag) rank = atomicAdd(&s_bins[key], 1u);
+    __syncthreads();
+    // exclusive prefix over the bins: one wave, 8 bins a lane
+    if (threadIdx.x < 64u) {
+        uint32_t c[kSortBins / 64], sum = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kSortBins / 64; ++k) { c[k] = s_bins[threadIdx.x * (kSortBins / 64) + k]; sum += c[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if ((int)threadIdx.x >= off) incl += v; }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < kSortBins / 64; ++k) { s_bins[threadIdx.x * (kSortBins / 64) + k] = run; run += c[k]; }
+        if (threadIdx.x == 63u) s_bins[kSortBins] = incl;                    // total
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u && s_bins[kSortBins] != 0u) s_bins[kSortBins + 1u] = atomicAdd(counter, s_bins[kSortBins]);
+    __syncthreads();
+    return flag ? s_bins[kSortBins + 1u] + s_bins[key] + rank : 0xFFFFFFFFu;
+}
+
 // A fresh path for work item `work` (first sample of its block).
 DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, Rng& g, V3& o, V3& d, float& tm) {
     const WorkItem it = decode_work(rd, work);
@@ -1747,6 +1778,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
                                                 uint32_t* __restrict__ count_out, uint32_t* __restrict__ next_work, uint32_t* __restrict__ head_to_zero,
                                                 unsigned long long* __restrict__ counters) {
     __shared__ uint32_t s_scan[kShadeThreads / 64 + 1];
+    __shared__ uint32_t s_bins[kSortBins + 2];
     extern __shared__ float4 s_tables[];
     // the scene's small tables, staged once per workgroup (LDS-DMA, linear copy): shade_segment then follows its chain of dependent
     // look-ups through LDS. The pointers become generic pointers into LDS (flat loads), the code that uses them does not change.
@@ -1833,7 +1865,16 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
 
     // ---- compaction: survivors go to the other pool densely (wave64 ballot + prefix, LDS scan across waves) ----
     {
-        const uint32_t dst = block_alloc(alive, count_out, s_scan);
+        uint32_t dst;
+        if (sc.sort_rays != 0u) {
+            // scenes walked from HBM: survivors ordered by (direction octant of the record arrays, 4 x 4 x 4 cell of the origin over the scene's bounds)
+            const uint32_t oct = ((d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u)) & sc.oct_mask;
+            const float k4 = 4.0f / 65536.0f;
+            const uint32_t cx = (uint32_t)fminf(fmaxf((o.x - sc.grid_lo[0]) * fast_rcp(sc.grid_scale[0]) * k4, 0.f), 3.f);
+            const uint32_t cy = (uint32_t)fminf(fmaxf((o.y - sc.grid_lo[1]) * fast_rcp(sc.grid_scale[1]) * k4, 0.f), 3.f);
+            const uint32_t cz = (uint32_t)fminf(fmaxf((o.z - sc.grid_lo[2]) * fast_rcp(sc.grid_scale[2]) * k4, 0.f), 3.f);
+            dst = block_alloc_sorted(alive, alive ? ((oct << 6) | (cz << 4) | (cy << 2) | cx) : 0u, count_out, s_bins);
+        } else dst = block_alloc(alive, count_out, s_scan);
         if (alive) store_path(out, qbase + dst, o, d, tm, s, g.n, depth, with_acc);
     }
     if (COUNT) {

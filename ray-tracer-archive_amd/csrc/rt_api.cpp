@@ -398,6 +398,7 @@ struct rti::SceneImage {
     std::vector<unsigned char> blob, eblob;
     uint32_t sb[12] = {0}, perlin_only = 0u, eb[5] = {0}, eb_rect_stride = 32u;
     uint32_t features = 0u;
+    bool sort_rays = true;
     rtw::WideTree wide; bool use_wide = false;     // 8-wide nodes for k_extend_wide (a static BVH that does not fit LDS)
 };
 void rti::scene_image_free(SceneImage* im) { delete im; }
@@ -411,6 +412,7 @@ int rti::scene_image_build(const RtSceneDesc* desc, const RtUploadOptions* optio
     if (rc != RT_OK) { err = "scene: " + cs.error; return rc; }
     im->in_lds = opt.lds_scene && lds_scene_bytes(cs) <= kLdsSceneBudget;
     im->features = scene_features(cs);
+    if (const char* e = getenv("RT_SORT_RAYS")) im->sort_rays = e[0] != '0';     // scripts/ only
     // RT_LAYOUT_WIDE_NODES: a static BVH in HBM (spheres / rects / triangles / boxes under box nodes only) walked 8 lanes to a ray over an
     // 8-wide tree (kernels.hip k_extend_wide) instead of the binary records below.
     if (!im->in_lds && opt.wide_nodes && opt.node16 && (im->features & ~(rtk::F_RECT | rtk::F_TRI)) == 0u && rtw::eligible(cs.nodes)) {
@@ -522,6 +524,7 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
     d.top_nodes = im.top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = im.top ? im.dn.n_top : 0u; d.n_records = im.c16 ? (uint32_t)im.n16.size() : im.dn.records();
     d.oct_stride = im.oct_stride; d.oct_mask = im.oct_mask;
+    d.sort_rays = (im.c16 && im.sort_rays) ? 1u : 0u;
     d.wide = im.use_wide ? (const uint4*)s->wide.p : nullptr; d.n_wide = im.use_wide ? im.wide.n_nodes : 0u;
     d.nodes16 = im.c16 ? 1u : 0u; for (int a = 0; a < 3; ++a) { d.grid_lo[a] = im.grid_lo[a]; d.grid_scale[a] = im.grid_scale[a]; }
     d.n_prologue = (uint32_t)cs.prologue.size();
