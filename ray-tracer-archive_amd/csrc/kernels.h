@@ -98,6 +98,8 @@ struct RenderDev {
     uint32_t total_items;   // in-image pixels of this shard * n_blocks
     uint32_t n_init;        // work items 0 .. n_init-1 are the pool's first fill; later ones are dealt to the queues (kernels.hip queue_item)
     uint32_t queue_cap;     // slots per queue
+    uint32_t q_lo, q_n, q_shift;   // this launch serves queues q_lo .. q_lo + q_n - 1 (q_n = 1 << q_shift: all 8, or one half of the pool when two
+                                   // halves are in flight on two streams, rt_api.cpp render_impl)
     uint32_t n_local_tiles;
     const uint32_t* tile_prefix;  // [n_local_tiles + 1]: in-image pixels in local tiles before lt
     uint32_t tile_slack;          // the tile of pixel q is within [q / ts^2, q / ts^2 + tile_slack] (edge tiles are clipped)
@@ -112,6 +114,7 @@ struct LaunchCfg {
     uint32_t features;        // F_* the scene needs
     bool scene_in_lds;
     uint32_t max_rays;        // upper bound of the rays in the queue of this launch of k_extend (sizes its grid when the queue is short)
+    uint32_t extend_share;    // 1: k_extend takes every resident slot of a CU; 2: half of them (the other half of the pool is being shaded meanwhile)
 };
 
 // what a launcher has to say about the error it has just returned (nullptr: nothing beyond hipGetErrorString)

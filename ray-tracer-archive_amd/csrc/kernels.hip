@@ -573,14 +573,14 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     constexpr bool LDS = MODE == M_LDS, TOP = MODE == M_TOP, C16 = MODE == M_C16;
     // The pool is kQueues independent queues (kernels.h): a wave serves the queue of its number mod kQueues, a DRAIN workgroup the
     // queue of its block number; every counter exists once per queue, 128 bytes apart.
-    if (blockIdx.x == 0 && threadIdx.x < kQueues) count_out_to_zero[threadIdx.x * kQStride] = 0u;   // the next k_shade appends to them
+    if (blockIdx.x == 0 && threadIdx.x < rd.q_n) count_out_to_zero[(rd.q_lo + threadIdx.x) * kQStride] = 0u;   // the next k_shade appends to them
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_all = blockIdx.x * (blockDim.x >> 6) + first_lane_u32(threadIdx.x >> 6);   // wave-uniform: keeps the queue bookkeeping in SGPRs
-    const uint32_t q = DRAIN ? (blockIdx.x & (kQueues - 1u)) : (wave_all & (kQueues - 1u));
+    const uint32_t q = rd.q_lo + ((DRAIN ? blockIdx.x : wave_all) & (rd.q_n - 1u));
     const uint32_t qbase = q * rd.queue_cap;
     const uint32_t count = count_ptr[q * kQStride];
     head += q * kQStride;
-    const uint32_t n_waves = max(1u, (gridDim.x * (blockDim.x >> 6)) / kQueues);   // waves serving this queue (the host launches a multiple of kQueues waves)
+    const uint32_t n_waves = max(1u, (gridDim.x * (blockDim.x >> 6)) >> rd.q_shift);   // waves serving this queue (the host launches a multiple of q_n waves)
     uint32_t chunk = count > kChunk * n_waves ? kChunk : max(64u, (count / (2u * n_waves)) & ~63u);
     // the first chunk of every wave is static (wave w owns [w*chunk, (w+1)*chunk)); the queue head counts from
     // behind them. Otherwise every wave of the grid would hit the head with a returning atomic in the same
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     const uint32_t head0 = n_waves * chunk;         // the dynamic part of the queue starts behind the static chunks
     // Short queue (the long tail of a render, hundreds of launches with a few thousand rays): a workgroup whose
     // waves own no static chunk has no dynamic chunk to fetch either — leave before staging the scene.
-    const uint32_t wave_id = wave_all / kQueues;     // this wave's number among the waves of its queue
+    const uint32_t wave_id = wave_all >> rd.q_shift;     // this wave's number among the waves of its queue
     if (!DRAIN) {
         // Short queues (the long tail of a render): a workgroup none of whose waves owns a static chunk or could fetch a dynamic one
         // leaves before staging the scene. Every thread evaluates the same test for all waves of the workgroup (no __syncthreads_or:
@@ -596,13 +596,13 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         bool any = false;
         const uint32_t w0 = blockIdx.x * (blockDim.x >> 6);
         for (uint32_t w = w0; w < w0 + (blockDim.x >> 6); ++w) {
-            const uint32_t cq = count_ptr[(w & (kQueues - 1u)) * kQStride];
+            const uint32_t cq = count_ptr[(rd.q_lo + (w & (rd.q_n - 1u))) * kQStride];
             const uint32_t ch = cq > kChunk * n_waves ? kChunk : max(64u, (cq / (2u * n_waves)) & ~63u);
-            any = any || (w / kQueues) * ch < cq || n_waves * ch < cq;
+            any = any || (w >> rd.q_shift) * ch < cq || n_waves * ch < cq;
         }
         if (!any) return;
     }
-    if (DRAIN && (blockIdx.x / kQueues) * blockDim.x >= count) return;      // lane i of the queue's workgroups carries path i
+    if (DRAIN && (blockIdx.x >> rd.q_shift) * blockDim.x >= count) return;      // lane i of the queue's workgroups carries path i
     const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
     const float4* spheres = reinterpret_cast<const float4*>(sc.spheres);
     const uint32_t top_bytes = TOP ? sc.n_top * 32u : 0u;
@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         prologue();
     };
     if (DRAIN) {
-        const uint32_t i = (blockIdx.x / kQueues) * blockDim.x + threadIdx.x;
+        const uint32_t i = (blockIdx.x >> rd.q_shift) * blockDim.x + threadIdx.x;
         if (i < count) {
             const Float4 ro = pool.ray_o[qbase + i], rdv = pool.ray_d[qbase + i], s0 = pool.s0[qbase + i];
             const uint32_t sd = pool.sd[qbase + i];
@@ -1179,13 +1179,13 @@ template <uint32_t FEAT, bool COUNT>
 __global__ void __launch_bounds__(256) k_extend_wide(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
                                                      uint32_t* __restrict__ count_out_to_zero, unsigned long long* __restrict__ counters, RenderDev rd) {
     __shared__ uint2 s_stack[(256 / 8) * kWideStackAll];
-    if (blockIdx.x == 0 && threadIdx.x < kQueues) count_out_to_zero[threadIdx.x * kQStride] = 0u;   // the next k_shade appends to them
+    if (blockIdx.x == 0 && threadIdx.x < rd.q_n) count_out_to_zero[(rd.q_lo + threadIdx.x) * kQStride] = 0u;   // the next k_shade appends to them
     const uint32_t lane = threadIdx.x & 63u, j = lane & 7u, gbase = lane & 56u;
     uint2* const stack = s_stack + (threadIdx.x >> 3) * kWideStackAll;          // this group's entries: x = child word, y = t_near bits; or x = node + 1, y = 0x80000000 | mask
     const uint32_t wave_all = blockIdx.x * (blockDim.x >> 6) + first_lane_u32(threadIdx.x >> 6);
-    const uint32_t q = wave_all & (kQueues - 1u), qbase = q * rd.queue_cap, count = count_ptr[q * kQStride];
+    const uint32_t q = rd.q_lo + (wave_all & (rd.q_n - 1u)), qbase = q * rd.queue_cap, count = count_ptr[q * kQStride];
     head += q * kQStride;
-    const uint32_t n_waves = max(1u, (gridDim.x * (blockDim.x >> 6)) / kQueues), wave_id = wave_all / kQueues;
+    const uint32_t n_waves = max(1u, (gridDim.x * (blockDim.x >> 6)) >> rd.q_shift), wave_id = wave_all >> rd.q_shift;
     constexpr uint32_t kC = RT_WIDE_CHUNK;
     uint32_t chunk = count > kC * n_waves ? kC : max(8u, (count / (2u * n_waves)) & ~7u);
     const uint32_t head0 = n_waves * chunk;          // the dynamic part of the queue starts behind the static first chunks
@@ -1811,15 +1811,15 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     // workgroup b shades 512 paths of queue b mod kQueues and compacts the survivors into the same queue of the other pool: one
     // counter pair per queue, so the same-address atomics of all the workgroups (one per 512 paths, ~11 ns each at the memory side:
     // 29 ms of a 39 ms kernel with ONE pair) spread over kQueues addresses
-    const uint32_t q = blockIdx.x & (kQueues - 1u), i = (blockIdx.x / kQueues) * blockDim.x + threadIdx.x, qbase = q * rd.queue_cap;
+    const uint32_t q = rd.q_lo + (blockIdx.x & (rd.q_n - 1u)), i = (blockIdx.x >> rd.q_shift) * blockDim.x + threadIdx.x, qbase = q * rd.queue_cap;
     const uint32_t count_in = count_in_ptr[q * kQStride];
     count_out += q * kQStride; next_work += q * kQStride;
     if (i == 0u) {
         head_to_zero[q * kQStride] = 0u;                                      // queue head of the next k_extend
         atomicAdd(&counters[CTR_SEGMENTS], (unsigned long long)count_in);     // world.hit calls so far
-        if (q == 0u) {
+        if (q == rd.q_lo) {
             uint32_t any = 0u;
-            for (uint32_t k = 0; k < kQueues; ++k) any |= count_in_ptr[k * kQStride];
+            for (uint32_t k = 0; k < rd.q_n; ++k) any |= count_in_ptr[(rd.q_lo + k) * kQStride];
             if (any) atomicAdd(&counters[CTR_ITERATIONS], 1ull);
         }
     }
@@ -1974,7 +1974,7 @@ static hipError_t launch_drain_c(const SceneDev& sc, const PoolDev& pool, const 
     static thread_local bool checked = false;
     if (!checked) { const hipError_t e = check_no_static_lds(k_extend<MODE, FEAT, COUNT, T, true>); if (e != hipSuccess) return e; checked = true; }
     // max_count = upper bound of the paths in ONE queue
-    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, T, true>), dim3(kQueues * ((max_count + T - 1u) / T)), dim3(T), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd, next_work);
+    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, T, true>), dim3(rd.q_n * ((max_count + T - 1u) / T)), dim3(T), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd, next_work);
     return hipGetLastError();
 }
 template <int MODE, uint32_t FEAT, bool COUNT>
@@ -2015,8 +2015,9 @@ static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, cons
     // the resident set, or fewer workgroups when the queue is short (the host's upper bound of it): a wave needs 64 rays to be worth
     // starting, and every workgroup started stages the scene and reads the queue size — the floor of the launches of a render's tail
     const uint32_t tpb = pick == 0 ? T0 : pick == 1 ? T1 : T2;
-    uint32_t groups = std::min<uint32_t>(cfg.n_cu * (uint32_t)nb[pick], std::max<uint32_t>(1u, (cfg.max_rays + tpb - 1u) / tpb));
-    const uint32_t gq = std::max<uint32_t>(1u, kQueues * 64u / tpb);     // workgroups that make up kQueues waves: every queue gets the same number of waves
+    const uint32_t per_cu = std::max<uint32_t>(1u, (uint32_t)nb[pick] / std::max<uint32_t>(1u, cfg.extend_share));
+    uint32_t groups = std::min<uint32_t>(cfg.n_cu * per_cu, std::max<uint32_t>(1u, (cfg.max_rays + tpb - 1u) / tpb));
+    const uint32_t gq = std::max<uint32_t>(1u, rd.q_n * 64u / tpb);     // workgroups that make up q_n waves: every queue gets the same number of waves
     groups = (groups + gq - 1u) / gq * gq;
     if (!kNoLds && pick == 2) return launch_extend_g<MODE, FEAT, COUNT, T2>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
     if (!kNoLds && pick == 1) return launch_extend_g<MODE, FEAT, COUNT, T1>(groups, lds_bytes, sc, pool, rd, count_ptr, head, cz, counters, stream);
@@ -2106,7 +2107,7 @@ static void launch_shade_t(uint32_t blocks, const SceneDev& sc, const PoolDev& i
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
                         const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, uint32_t* hz, unsigned long long* counters, bool count,
                         hipStream_t stream) {
-    const uint32_t blocks = kQueues * ((max_count + kShadeThreads - 1u) / kShadeThreads);   // max_count = upper bound of the paths in ONE queue
+    const uint32_t blocks = rd.q_n * ((max_count + kShadeThreads - 1u) / kShadeThreads);   // max_count = upper bound of the paths in ONE queue
     if (blocks == 0u) return hipSuccess;
     const uint32_t v = pick_variant(cfg.features);
     if (v == 0u) launch_shade_t<0u>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);

@@ -144,6 +144,7 @@ int rt_ctx_destroy(RtCtx* ctx) {
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->h_words) (void)hipHostFree(ctx->h_words);
     ctx->comm_words.release();
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -701,11 +702,12 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     cfg.n_cu = (uint32_t)ctx->n_cu; cfg.extend_geometry = extend_geometry; cfg.features = scene->features; cfg.scene_in_lds = scene->in_lds;
 
     size_t ev_used = 0;
-    auto next_event = [&](hipEvent_t& ev) -> hipError_t {
+    auto next_event_on = [&](hipEvent_t& ev, hipStream_t st) -> hipError_t {
         if (ev_used == ctx->events.size()) { hipEvent_t e; hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return r; ctx->events.push_back(e); }
         ev = ctx->events[ev_used++];
-        return hipEventRecord(ev, ctx->stream);
+        return hipEventRecord(ev, st);
     };
+    auto next_event = [&](hipEvent_t& ev) -> hipError_t { return next_event_on(ev, ctx->stream); };
     struct Span { hipEvent_t a, b; int kind; };
     std::vector<Span> spans;
 
@@ -713,25 +715,16 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     if (timing) HIP_TRY(ctx, next_event(e0));
     const uint32_t n_init = (uint32_t)std::min<uint64_t>(P, total_items);
     rd.n_init = n_init;
+    rd.q_lo = 0u; rd.q_n = rtk::kQueues; rd.q_shift = 3u;
     HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, n_init, c_next_work, c_count[0], ctx->stream));
     if (timing) { HIP_TRY(ctx, next_event(e1)); spans.push_back({e0, e1, 2}); }
-    // upper bound of the size of the LARGEST queue from here on (a queue never grows): it sizes the grids, and 0 ends the render
-    uint32_t live = std::min<uint32_t>(rd.queue_cap, (n_init + rtk::kQueues - 1u) / rtk::kQueues + 512u);
-    int cur = 0;
     // The host never waits for an iteration it has just enqueued: the kernels read the pool size from device memory and size-check
     // themselves, so the host only needs (a) an UPPER BOUND of the pool size to size k_shade's grid and (b) to learn that it has
     // reached 0. After every iteration the size is copied to a pinned ring slot behind an event; before enqueuing the next
     // iteration the host takes whatever copies have landed (the size never grows, so an older value is a valid bound) and blocks
     // only when it is kAhead iterations ahead. (Batches of 4, 8, 16, 32 iterations with a blocking read in between sized eight
     // launches of k_shade by the 268 M paths of the start while 5 M were alive — 0.6 ms each for empty workgroups.)
-    constexpr uint32_t kAhead = 3, kRing = 8;
-    struct Pending { hipEvent_t ev; uint32_t ring; };
-    std::vector<Pending> pending;      // oldest first
-    size_t pending_head = 0;
-    auto take = [&](const Pending& pd_) {
-        uint32_t m = 0; for (uint32_t k = 0; k < rtk::kQueues; ++k) m = std::max(m, ctx->h_count[pd_.ring * rtk::kQueues + k]);
-        live = std::min(live, m);
-    };
+    constexpr uint32_t kAhead = 3, kRing = 4;
     // The tail goes to the drain kernel: once at most `drain_at` paths are alive, ONE launch carries each of them to its end
     // (kernels.hip DRAIN). RT_FLAG_FUSED hands the whole render to it (a diagnostic: bit-identical frame, slower).
     // Measured on the bench workload (LDS-resident scene): hand-over at 2^18 paths 103.2 ms, never 104.1, at 2^21 106.5, at 2^24 121. Scene in
@@ -744,42 +737,87 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     // make such pixels depend on WHEN the hand-over happens, so a wide scene's wavefront loop runs to its end
     if (scene->dev.wide != nullptr) drain_at = 0u;
     if (prm->flags & RT_FLAG_FUSED) drain_at = 0xFFFFFFFFu;
-    uint32_t launched = 0, drained = 0;
+
+    // ---- lanes: the pool's 8 queues as ONE wavefront loop, or as TWO halves of 4 queues on two streams ------------------------------------
+    // k_extend (an LDS-resident scene) is bound by the LDS array and VALU issue and touches HBM for 40 bytes a segment; k_shade waits on
+    // memory latency for 58 % of its wave time and leaves the LDS idle. Run one after the other each has the chip to itself and leaves
+    // the other's unit unused. With two halves in flight, half A's k_shade runs WHILE half B's k_extend does: k_extend is launched with
+    // half of a CU's resident slots (cfg.extend_share = 2) and the shading workgroups of the other half fill the rest. The extends of the
+    // two lanes are chained by events (A1, B1, A2, B2, ...) so that at any time one extend and one shade are in flight; a lane's shade
+    // follows its extend in stream order. The picture does not depend on any of this (per-item sums; RNG keyed by pixel and sample).
+    struct Pending { hipEvent_t ev; uint32_t ring; };
+    struct Lane {
+        hipStream_t st; uint32_t q_lo, q_n, q_shift;
+        uint32_t live; int cur; uint32_t launched, drained; bool done;
+        std::vector<Pending> pending; size_t head;
+    };
+    bool overlap = false;
+    if (const char* e = getenv("RT_OVERLAP")) overlap = e[0] == '1';
+    if (prm->flags & RT_FLAG_FUSED) overlap = false;
+    if (overlap && !ctx->stream2) { if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) overlap = false; }
+    const uint32_t n_lanes = overlap ? 2u : 1u, per_lane = rtk::kQueues / n_lanes;
+    Lane lanes[2];
+    // upper bound of the size of the LARGEST queue from here on (a queue never grows): it sizes the grids, and 0 ends the render
+    const uint32_t live0 = std::min<uint32_t>(rd.queue_cap, (n_init + rtk::kQueues - 1u) / rtk::kQueues + 512u);
+    for (uint32_t l = 0; l < n_lanes; ++l) lanes[l] = Lane{l == 0 ? ctx->stream : ctx->stream2, l * per_lane, per_lane, per_lane == 8u ? 3u : 2u, live0, 0, 0u, 0u, false, {}, 0};
+    if (overlap) {   // the second stream starts behind k_generate
+        hipEvent_t eg = nullptr; HIP_TRY(ctx, next_event(eg));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, eg, 0));
+    }
+    cfg.extend_share = overlap ? 2u : 1u;
     std::vector<uint32_t> iter_live;     // RT_DEBUG_ITER=1 (with RT_FLAG_TIMING): the host's bound of the largest queue at every iteration
-    while (live > 0) {
-        while (pending_head < pending.size() && hipEventQuery(pending[pending_head].ev) == hipSuccess) take(pending[pending_head++]);
-        if (live == 0) break;
-        if (pending.size() - pending_head >= kAhead) {
-            HIP_TRY(ctx, hipEventSynchronize(pending[pending_head].ev));
-            take(pending[pending_head++]);
-            if (live == 0) break;
+    hipEvent_t last_extend = nullptr;    // overlap: end of the most recent k_extend of either lane
+    auto take = [&](Lane& L, const Pending& pd_) {
+        uint32_t m = 0; for (uint32_t k = 0; k < L.q_n; ++k) m = std::max(m, ctx->h_count[pd_.ring * rtk::kQueues + L.q_lo + k]);
+        L.live = std::min(L.live, m);
+    };
+    // one step of a lane: nothing (done), the drain launch, or one wavefront iteration. Returns a HIP/RT status through `rc`.
+    auto step = [&](Lane& L, uint32_t lane_index) -> int {
+        while (L.head < L.pending.size() && hipEventQuery(L.pending[L.head].ev) == hipSuccess) take(L, L.pending[L.head++]);
+        if (L.live != 0u && L.pending.size() - L.head >= kAhead) {
+            HIP_TRY(ctx, hipEventSynchronize(L.pending[L.head].ev));
+            take(L, L.pending[L.head++]);
         }
-        if ((uint64_t)live * rtk::kQueues <= drain_at) {
+        if (L.live == 0u) { L.done = true; return RT_OK; }
+        rtk::RenderDev r = rd; r.q_lo = L.q_lo; r.q_n = L.q_n; r.q_shift = L.q_shift;
+        if ((uint64_t)L.live * rtk::kQueues <= drain_at) {
             hipEvent_t ea = nullptr, eb = nullptr;
-            if (timing) HIP_TRY(ctx, next_event(ea));
-            LAUNCH_TRY(rtk::launch_drain(cfg, scene->dev, pd[cur], rd, live, c_count[cur], c_head, c_count[1 - cur], c_next_work, c64, counting, ctx->stream));
-            if (timing) { HIP_TRY(ctx, next_event(eb)); spans.push_back({ea, eb, 3}); }
-            drained = live * rtk::kQueues;
-            break;
+            if (timing) HIP_TRY(ctx, next_event_on(ea, L.st));
+            LAUNCH_TRY(rtk::launch_drain(cfg, scene->dev, pd[L.cur], r, L.live, c_count[L.cur], c_head, c_count[1 - L.cur], c_next_work, c64, counting, L.st));
+            if (timing) { HIP_TRY(ctx, next_event_on(eb, L.st)); spans.push_back({ea, eb, 3}); }
+            L.drained = L.live * L.q_n;
+            L.done = true;
+            return RT_OK;
         }
         hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
-        if (timing) HIP_TRY(ctx, next_event(ea));
-        cfg.max_rays = (uint32_t)std::min<uint64_t>((uint64_t)live * rtk::kQueues, 0xFFFFFFFFull);
-        LAUNCH_TRY(rtk::launch_extend(cfg, scene->dev, pd[cur], rd, c_count[cur], c_head, c_count[1 - cur], c64, counting, ctx->stream));
-        if (timing) HIP_TRY(ctx, next_event(eb));
-        HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[cur], pd[1 - cur], rd, live, c_count[cur], c_count[1 - cur], c_next_work, c_head, c64, counting,
-                                       ctx->stream));
-        if (timing) { HIP_TRY(ctx, next_event(ec)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); iter_live.push_back(live); }
-        cur = 1 - cur;
-        const uint32_t ring = launched % kRing;
-        HIP_TRY(ctx, hipMemcpy2DAsync(ctx->h_count + ring * rtk::kQueues, sizeof(uint32_t), c_count[cur], kLine, sizeof(uint32_t), rtk::kQueues, hipMemcpyDeviceToHost,
-                                      ctx->stream));   // the kQueues pool sizes, one per line
+        if (overlap && last_extend) HIP_TRY(ctx, hipStreamWaitEvent(L.st, last_extend, 0));     // extends alternate between the lanes
+        if (timing) HIP_TRY(ctx, next_event_on(ea, L.st));
+        cfg.max_rays = (uint32_t)std::min<uint64_t>((uint64_t)L.live * L.q_n, 0xFFFFFFFFull);
+        LAUNCH_TRY(rtk::launch_extend(cfg, scene->dev, pd[L.cur], r, c_count[L.cur], c_head, c_count[1 - L.cur], c64, counting, L.st));
+        if (timing || overlap) HIP_TRY(ctx, next_event_on(eb, L.st));
+        if (overlap) last_extend = eb;
+        HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[L.cur], pd[1 - L.cur], r, L.live, c_count[L.cur], c_count[1 - L.cur], c_next_work, c_head, c64, counting, L.st));
+        if (timing) { HIP_TRY(ctx, next_event_on(ec, L.st)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); if (lane_index == 0u) iter_live.push_back(L.live); }
+        L.cur = 1 - L.cur;
+        const uint32_t ring = (L.launched % kRing) + lane_index * kRing;
+        HIP_TRY(ctx, hipMemcpy2DAsync(ctx->h_count + ring * rtk::kQueues, sizeof(uint32_t), c_count[L.cur], kLine, sizeof(uint32_t), rtk::kQueues, hipMemcpyDeviceToHost,
+                                      L.st));   // the kQueues pool sizes, one per line (a lane reads its own queues' entries)
         hipEvent_t ev = nullptr;
-        HIP_TRY(ctx, next_event(ev));
-        pending.push_back({ev, ring});
-        ++launched;
-        if (launched > 100000000u) return set_err(ctx, RT_ERR_DEVICE, "render loop did not terminate");
+        HIP_TRY(ctx, next_event_on(ev, L.st));
+        L.pending.push_back({ev, ring});
+        if (++L.launched > 100000000u) return set_err(ctx, RT_ERR_DEVICE, "render loop did not terminate");
+        return RT_OK;
+    };
+    for (;;) {
+        bool any = false;
+        for (uint32_t l = 0; l < n_lanes; ++l) if (!lanes[l].done) { const int rc = step(lanes[l], l); if (rc != RT_OK) return rc; any = any || !lanes[l].done; }
+        if (!any) break;
     }
+    if (overlap) {   // the resolve (first stream) waits for the second lane
+        hipEvent_t ej = nullptr; HIP_TRY(ctx, next_event_on(ej, ctx->stream2));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ej, 0));
+    }
+    const uint32_t launched = lanes[0].launched + (n_lanes > 1 ? lanes[1].launched : 0u), drained = lanes[0].drained + (n_lanes > 1 ? lanes[1].drained : 0u);
     hipEvent_t r0 = nullptr, r1 = nullptr;
     if (timing) HIP_TRY(ctx, next_event(r0));
     if (sc > 1) HIP_TRY(ctx, hipMemsetAsync(d_out, 0, (size_t)tl.n_local * tl.ts * tl.ts * 3 * sizeof(float), ctx->stream));   // clipped pixels of edge tiles stay 0

@@ -31,6 +31,7 @@ struct DevBuf {
 struct RtCtx {
     int device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
+    hipStream_t stream2 = nullptr;               // the second lane of a render whose pool halves overlap (rt_api.cpp render_impl); made on demand
     int n_cu = 256;
     std::string err;
     // grow-only work buffers

@@ -264,7 +264,10 @@ bool rti::runtime_libraries_ok(std::string& listing, std::string& why) {
     for (const char* stem : {"libamdhip64.so", "libhsa-runtime64.so", "librccl.so"}) {
         const std::vector<std::string> have = mapped(stem);
         for (const std::string& p : have) listing += p + "\n";
-        if (have.size() > 1 && why.empty()) {
+        // libhsa-runtime64 is listed but not judged: under rocprofv3 the profiler's tool library brings the system's copy next to the one
+        // the HIP runtime in use was linked against, and only the latter is ever initialised. Two HIP runtimes (or two RCCLs) are two
+        // sets of device state in use at once.
+        if (have.size() > 1 && why.empty() && std::strcmp(stem, "libhsa-runtime64.so") != 0) {
             ok = false;
             why = std::string("two copies of ") + stem + " are mapped in this process (" + have[0] + ", " + have[1] + "): two ROCm runtimes with separate device state, "
                   "which ends in heap corruption at exit. PyTorch bundles its own copies under other file names; load it BEFORE this library (its copies carry the "

@@ -47,6 +47,14 @@ def test_rccl_communicator_and_exchange(pkg, book1):
     assert len(uid) == A.RT_COMM_ID_BYTES and any(uid)
     ctx.comm_init_rank(uid, 0, 1)
     ctx.comm_selftest()
+    # ONE ROCm runtime stack in the process ("the abort of round 2"): with the communicator up there is exactly one
+    # mapped libamdhip64 and one librccl — torch's, which librt_hip.so and its dlopen share because conftest imports torch first
+    libs, ok = pkg.runtime_libraries()
+    assert ok, libs
+    assert len([l for l in libs if "libamdhip64" in l]) == 1 and len([l for l in libs if "librccl" in l]) == 1, libs
+    maps = open("/proc/self/maps").read()
+    assert len({ln.split()[-1] for ln in maps.splitlines() if "libamdhip64" in ln}) == 1
+    assert len({ln.split()[-1] for ln in maps.splitlines() if "librccl" in ln}) == 1
     # rt_render_gather with a world of one: the frame in caller-owned device memory, f32 and RGB8
     import torch
     from importlib import import_module
