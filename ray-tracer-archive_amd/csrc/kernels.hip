@@ -965,7 +965,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         // passes and the lanes they serve, per kind (RT_STAMPS builds run without COUNT: its slots carry these)
         if (do_prims) {
             for (uint32_t k = rtd::LT_SPHERE; k <= rtd::LT_MEDIUM; ++k) {
-                const uint32_t c = (uint32_t)__popcll(__ballot(pl != 0u && (pl >> 28) == k && (serve == 0u || k == serve)));
+                const uint32_t kk = k == rtd::LT_RECT ? (uint32_t)rtd::LT_BOX : k;       // (a Box counts in the rects' slot: its sides)
+                const uint32_t c = (uint32_t)__popcll(__ballot(pl != 0u && ((pl >> 28) == k || (pl >> 28) == kk) && (serve == 0u || (pl >> 28) == serve)));
                 if (c != 0u && lane == 0u) { st_pass[k - 1u] += 1ull; st_lanes[k - 1u] += c; }
             }
             if (lane == 0u) st_pass[5]++;

@@ -25,14 +25,16 @@ pytestmark = pytest.mark.gpu
 # per crop, worst crop of the config: mean|diff| of the per-pixel mean, pixels off by > 2e-3, 8-bit channels within +-2, then the counters of the
 # crop rendered as a one-tile shard against the oracle's: segments (relative), AABB tests and primitive tests (relative excess)
 TOL = {
-    "C2": dict(mean=4e-5, bad=1e-3, bit8=0.999, seg=6e-5, node=1e-3, prim=1e-3, zmean=0.05, se4=1e-3),       # measured 1.9e-5, 0, 1.0, 2.4e-5, 3e-4, 1e-4
+    "C2": dict(mean=4e-5, bad=1e-3, bit8=0.999, seg=6e-5, node=1e-3, prim=1e-3, zmean=0.015, se4=1e-3),       # measured 1.9e-5, 0, 1.0, 2.4e-5, 2.8e-4, 1.4e-4, z 0.0068, 0
     # the book-2 frame is nearly black under the reference's DiffuseLight (front face only): mean radiance ~2e-3, so sqrt gamma turns
     # tiny linear differences into 8-bit steps; the r = 5000 fog sphere makes the scene extent (hence the box padding) large
     "C3": dict(mean=1.5e-4, bad=0.027, bit8=0.93, seg=5e-3, node=0.015, prim=0.015),     # measured 7.3e-5, 0.014, 0.965, 2.4e-3, 7.0e-3, 6.6e-3
-    # the lit twins (tests/crops.py): FlipFace around the light, everything else as the literal scenes. PROVISIONAL until measured.
-    "C3lit": dict(mean=6e-3, bad=1.0, bit8=0.94, seg=6e-3, node=0.03, prim=0.03, zmean=0.25, se4=2e-3),
-    "SMOKElit": dict(mean=1e-4, bad=0.03, bit8=0.999, seg=1e-4, node=1e-9, prim=1e-4, zmean=0.05, se4=1e-3),
-    "C4": dict(mean=2.6e-4, bad=0.014, bit8=0.997, seg=2e-5, node=1e-9, prim=2e-5),    # measured 1.3e-4, 6.8e-3, 0.9987, 7e-6, 0 (no BVH), 8e-6
+    # the lit twins (tests/crops.py): FlipFace around the light, everything else as the literal scenes. At radiance 0.2-1.0 the absolute
+    # "pixels off by > 2e-3" says nothing (bad = 1.0 switches it off for C3lit); the scale there is the pixel's standard error (zmean, se4).
+    # C3lit's worst crop is the one over the 1000-sphere cluster, where 2 % of the paths diverge from the f64 oracle's
+    "C3lit": dict(mean=6e-3, bad=1.0, bit8=0.94, seg=6e-3, node=0.015, prim=0.015, zmean=0.15, se4=1e-3),   # measured 2.8e-3, -, 0.9696 (other crops >= 0.9997), 2.7e-3, 6.5e-3, 6.9e-3, z 0.068, 0
+    "SMOKElit": dict(mean=6e-5, bad=0.025, bit8=0.999, seg=7e-5, node=1e-9, prim=7e-5, zmean=0.005, se4=1e-3),   # measured 3.0e-5, 0.011, 0.9998, 3.3e-5, 0, 3.3e-5, z 0.0012, 0
+    "C4": dict(mean=2.6e-4, bad=0.014, bit8=0.997, seg=2e-5, node=1e-9, prim=2e-5, zmean=0.01, se4=1e-3),    # measured 1.3e-4, 6.8e-3, 0.9987, 7e-6, 0 (no BVH), 5e-6, z 0.0032, 0
     # C5 walks 16-byte compressed records (corners on a u16 grid over the scene): boxes a grid step looser, so more tests — culling only
     "C5": dict(mean=4e-4, bad=0.025, bit8=0.99, seg=7e-4, node=0.05, prim=0.16),       # measured 2.0e-4, 0.012, 0.996, 3.4e-4, 2.4e-2, 8.1e-2
 }
