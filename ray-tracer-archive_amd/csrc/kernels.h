@@ -96,7 +96,9 @@ struct RenderDev {
     uint32_t block_shift;   // a work item covers 1 << block_shift consecutive samples of one pixel
     uint32_t n_blocks;      // work items per pixel = ceil(spp >> block_shift)
     uint32_t total_items;   // in-image pixels of this shard * n_blocks
-    uint32_t n_init;        // work items 0 .. n_init-1 are the pool's first fill; later ones are dealt to the queues (kernels.hip queue_item)
+    uint32_t n_init;        // work items 0 .. n_init-1 are the pool's first fill
+    uint32_t lineage;       // the path that finishes work item w goes on with item w + lineage (< total_items): every slot of the first fill owns the
+                            // items of its residue class, so a finished path finds its next item without asking anybody (no atomic, no barrier)
     uint32_t queue_cap;     // slots per queue
     uint32_t q_lo, q_n, q_shift;   // this launch serves queues q_lo .. q_lo + q_n - 1 (q_n = 1 << q_shift: all 8, or one half of the pool when two
                                    // halves are in flight on two streams, rt_api.cpp render_impl)
@@ -119,16 +121,16 @@ struct LaunchCfg {
 
 // what a launcher has to say about the error it has just returned (nullptr: nothing beyond hipGetErrorString)
 const char* launch_note();
-hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_init, uint32_t* next_work, uint32_t* out_count, hipStream_t stream);
+hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_init, uint32_t* out_count, hipStream_t stream);
 // One wavefront iteration = launch_extend then launch_shade. No memsets in between: k_extend zeroes
 // the count the following k_shade appends to, k_shade zeroes the queue head of the next k_extend.
 hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                          uint32_t* head, uint32_t* count_out_to_zero, unsigned long long* counters, bool count, hipStream_t stream);
 // The rest of a render in one launch: every path of `pool` (at most max_count) is carried to its end by one lane (kernels.hip DRAIN).
 hipError_t launch_drain(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, uint32_t max_count, const uint32_t* count_ptr,
-                        uint32_t* head, uint32_t* count_out_to_zero, uint32_t* next_work, unsigned long long* counters, bool count, hipStream_t stream);
+                        uint32_t* head, uint32_t* count_out_to_zero, unsigned long long* counters, bool count, hipStream_t stream);
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
-                        const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, uint32_t* head_to_zero, unsigned long long* counters,
+                        const uint32_t* count_in, uint32_t* count_out, uint32_t* head_to_zero, unsigned long long* counters,
                         bool count, hipStream_t stream);
 hipError_t launch_resolve(const RenderDev& rd, float* out, uint32_t n_valid_pixels, hipStream_t stream);
 hipError_t launch_write_color(const float* rgb_sum, uint32_t n_pixels, uint32_t spp, uint8_t* rgb8, hipStream_t stream);

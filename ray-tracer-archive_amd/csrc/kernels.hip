@@ -455,14 +455,6 @@ DEVI uint32_t item_slot(const RenderDev& rd, uint32_t item) {
     return rd.tile_prefix[lt] * rd.n_blocks + blk * (w * h) + p;
 }
 
-// Work items beyond the pool's first fill (items 0 .. n_init-1) are dealt to the queues in runs of 64: queue q's t-th draw is item
-// n_init + ((t / 64) * kQueues + q) * 64 + t % 64 (so 64 consecutive draws of a queue still cover one 8x8 pixel square); valid while
-// below total_items. Which queue renders an item does not matter to the picture (per-item sums, RNG keyed by pixel and sample).
-DEVI uint32_t queue_item(const RenderDev& rd, uint32_t q, uint32_t t) {
-    const uint64_t item = (uint64_t)rd.n_init + ((uint64_t)(t >> 6) * kQueues + q) * 64u + (t & 63u);
-    return item < (uint64_t)rd.total_items ? (uint32_t)item : 0xFFFFFFFFu;
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_extend — world.hit for the whole pool
 // ------------------------------------------------------------------------------------------------
@@ -568,7 +560,7 @@ constexpr int kShadeBatch = 16;   // DRAIN: lanes on DONE that trigger a shading
 template <int MODE, uint32_t FEAT, bool COUNT, uint32_t TPB, bool DRAIN>
 __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
                                                  uint32_t* __restrict__ head, uint32_t* __restrict__ count_out_to_zero,
-                                                 unsigned long long* __restrict__ counters, RenderDev rd, uint32_t* __restrict__ next_work) {
+                                                 unsigned long long* __restrict__ counters, RenderDev rd) {
     extern __shared__ float4 lds[];
     constexpr bool LDS = MODE == M_LDS, TOP = MODE == M_TOP, C16 = MODE == M_C16;
     // The pool is kQueues independent queues (kernels.h): a wave serves the queue of its number mod kQueues, a DRAIN workgroup the
@@ -1079,24 +1071,17 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     if (sh & SH_FINISHED) {
                         if (COUNT) c_samples++;
                         if (finish_sample(rd, ps, g, depth, L, so, sd, tm)) {
-                            rd.blocksum[item_slot(rd, ps.work)] = Float4{ps.acc.x, ps.acc.y, ps.acc.z, 0.f};
+                            const uint32_t w = item_slot(rd, ps.work);
+                            rd.blocksum[w] = Float4{ps.acc.x, ps.acc.y, ps.acc.z, 0.f};
                             want = true;
+                            // regeneration: the next item of this path's lineage (kernels.h RenderDev::lineage), if there is one
+                            const uint32_t next = w + rd.lineage;
+                            if (next < rd.total_items) { start_item(rd, next, ps, g, so, sd, tm); depth = 0; want = false; }
                         }
                     }
                     o = so; d = sd;
                 }
-                // regeneration: one atomic per wave for the lanes whose item is complete
-                const uint64_t wm = __ballot(want);
-                if (wm != 0ull) {
-                    uint32_t base = 0;
-                    if (lane == (uint32_t)__builtin_ctzll(wm)) base = atomicAdd(next_work + q * kQStride, (uint32_t)__popcll(wm));
-                    base = (uint32_t)__shfl((int)base, __builtin_ctzll(wm));
-                    if (want) {
-                        const uint32_t work = queue_item(rd, q, base + lane_rank(wm));
-                        if (work < rd.total_items) { start_item(rd, work, ps, g, o, d, tm); depth = 0; }
-                        else go_idle();                                      // nothing left: the lane retires
-                    }
-                }
+                if (want) go_idle();                                         // its lineage is finished: the lane retires
                 if (lane_done && !is_idle()) begin_walk();
             }
             if (__ballot(!is_idle()) == 0ull) break;
@@ -1438,7 +1423,7 @@ DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, Rng& g, V
     s.work = item_id(rd, it.x, it.y, it.blk); s.sample = sample; s.from = 0u;
 }
 
-__global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, RenderDev rd, uint32_t n_init, uint32_t* __restrict__ next_work, uint32_t* __restrict__ out_count) {
+__global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, RenderDev rd, uint32_t n_init, uint32_t* __restrict__ out_count) {
     // the first fill of the pool needs no allocator: work item i goes to queue (i / 512) mod kQueues, slot (i / 4096) * 512 + i mod 512
     // of it (the host passes n_init <= total_items), and the counters get their values from kQueues threads. (With the atomics +
     // barriers of block_alloc this kernel was latency-bound: 6.0 ms for 268 M paths at 41 % of the HBM write rate.)
@@ -1446,7 +1431,6 @@ __global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, Render
     if (i < kQueues) {
         const uint32_t full = (n_init / (512u * kQueues)) * 512u, rem = n_init % (512u * kQueues);
         out_count[i * kQStride] = full + min(512u, rem > i * 512u ? rem - i * 512u : 0u);
-        next_work[i * kQStride] = 0u;
     }
     if (i < n_init) {
         PathState s; V3 o, d; float tm; Rng g;
@@ -1776,7 +1760,7 @@ template <uint32_t FEAT, bool COUNT>
 #endif
 __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, 8)))
 __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in, PoolDev out, RenderDev rd, const uint32_t* __restrict__ count_in_ptr,
-                                                uint32_t* __restrict__ count_out, uint32_t* __restrict__ next_work, uint32_t* __restrict__ head_to_zero,
+                                                uint32_t* __restrict__ count_out, uint32_t* __restrict__ head_to_zero,
                                                 unsigned long long* __restrict__ counters) {
     __shared__ uint32_t s_scan[kShadeThreads / 64 + 1];
     __shared__ uint32_t s_bins[kSortBins + 2];
@@ -1814,7 +1798,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     // 29 ms of a 39 ms kernel with ONE pair) spread over kQueues addresses
     const uint32_t q = rd.q_lo + (blockIdx.x & (rd.q_n - 1u)), i = (blockIdx.x >> rd.q_shift) * blockDim.x + threadIdx.x, qbase = q * rd.queue_cap;
     const uint32_t count_in = count_in_ptr[q * kQStride];
-    count_out += q * kQStride; next_work += q * kQStride;
+    count_out += q * kQStride;
     if (i == 0u) {
         head_to_zero[q * kQStride] = 0u;                                      // queue head of the next k_extend
         atomicAdd(&counters[CTR_SEGMENTS], (unsigned long long)count_in);     // world.hit calls so far
@@ -1828,7 +1812,6 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     const bool with_acc = rd.block_shift != 0u;
     PathState s{}; V3 o = v3(0, 0, 0), d = v3(0, 0, 1); float tm = 0.f;
     unsigned long long c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
-    bool want_work = false;
     Rng g; g.s = 0; g.n = 0u; uint32_t depth = 0u;
     if (alive) {
         const Float4 ro = in.ray_o[qbase + i], rdv = in.ray_d[qbase + i], s0 = in.s0[qbase + i];
@@ -1848,19 +1831,15 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
             // one sample done
             if (COUNT) c_samples++;
             if (finish_sample(rd, s, g, depth, L, o, d, tm)) {
-                rd.blocksum[item_slot(rd, s.work)] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
-                want_work = true;
+                const uint32_t w = item_slot(rd, s.work);
+                rd.blocksum[w] = Float4{s.acc.x, s.acc.y, s.acc.z, 0.f};
+                // ---- regeneration: the path goes on with the next item of its lineage (w + lineage), which no other path will ever ask for:
+                // no counter, no atomic, no barrier (round 2 drew items from a per-queue counter: one returning atomic and three barriers
+                // per workgroup) ----
+                const uint32_t next = w + rd.lineage;
+                if (next < rd.total_items) { start_item(rd, next, s, g, o, d, tm); depth = 0u; }
+                else alive = false;
             }
-        }
-    }
-
-    // ---- regeneration: a slot whose block is complete draws a new work item (one atomic per workgroup) ----
-    {
-        const uint32_t t = block_alloc(want_work, next_work, s_scan);
-        if (want_work) {
-            const uint32_t work = queue_item(rd, q, t);
-            if (work < rd.total_items) { start_item(rd, work, s, g, o, d, tm); depth = 0u; }
-            else alive = false;
         }
     }
 
@@ -1963,19 +1942,19 @@ template <class K> static hipError_t check_no_static_lds(K kernel) {
 template <int MODE, uint32_t FEAT, bool COUNT, uint32_t TPB>
 static hipError_t launch_extend_g(uint32_t n_groups, size_t lds_bytes, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
-    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, TPB, false>), dim3(n_groups), dim3(TPB), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd, (uint32_t*)nullptr);
+    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, TPB, false>), dim3(n_groups), dim3(TPB), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
     return hipGetLastError();
 }
 // the drain form: one lane per path of the pool (upper bound max_count; the kernel reads the real count), 256-thread groups
 template <int MODE, uint32_t FEAT, bool COUNT>
 static hipError_t launch_drain_c(const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, uint32_t max_count, const uint32_t* count_ptr, uint32_t* head, uint32_t* cz,
-                                 uint32_t* next_work, unsigned long long* counters, hipStream_t stream) {
+                                 unsigned long long* counters, hipStream_t stream) {
     const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u + sc.ext_blob_bytes) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
     constexpr uint32_t T = kExtendThreads;
     static thread_local bool checked = false;
     if (!checked) { const hipError_t e = check_no_static_lds(k_extend<MODE, FEAT, COUNT, T, true>); if (e != hipSuccess) return e; checked = true; }
     // max_count = upper bound of the paths in ONE queue
-    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, T, true>), dim3(rd.q_n * ((max_count + T - 1u) / T)), dim3(T), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd, next_work);
+    hipLaunchKernelGGL((k_extend<MODE, FEAT, COUNT, T, true>), dim3(rd.q_n * ((max_count + T - 1u) / T)), dim3(T), lds_bytes, stream, sc, pool, count_ptr, head, cz, counters, rd);
     return hipGetLastError();
 }
 template <int MODE, uint32_t FEAT, bool COUNT>
@@ -2083,11 +2062,11 @@ hipError_t launch_extend(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev
 }
 
 hipError_t launch_drain(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, uint32_t max_count, const uint32_t* count_ptr,
-                        uint32_t* head, uint32_t* cz, uint32_t* next_work, unsigned long long* counters, bool count, hipStream_t stream) {
+                        uint32_t* head, uint32_t* cz, unsigned long long* counters, bool count, hipStream_t stream) {
     if (max_count == 0u) return hipSuccess;
     const uint32_t v = pick_variant(cfg.features);
-#define RT_DRN(M, F) (count ? launch_drain_c<M, F, true>(sc, pool, rd, max_count, count_ptr, head, cz, next_work, counters, stream) \
-                            : launch_drain_c<M, F, false>(sc, pool, rd, max_count, count_ptr, head, cz, next_work, counters, stream))
+#define RT_DRN(M, F) (count ? launch_drain_c<M, F, true>(sc, pool, rd, max_count, count_ptr, head, cz, counters, stream) \
+                            : launch_drain_c<M, F, false>(sc, pool, rd, max_count, count_ptr, head, cz, counters, stream))
 #define RT_DRN_V(M) (v == 0u ? RT_DRN(M, 0u) : v == kVariantMesh ? RT_DRN(M, kVariantMesh) : v == kVariantBox ? RT_DRN(M, kVariantBox) : RT_DRN(M, F_ALL))
     if (cfg.scene_in_lds) return RT_DRN_V(M_LDS);
     if (sc.nodes16) return RT_DRN_V(M_C16);
@@ -2099,29 +2078,29 @@ hipError_t launch_drain(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev&
 
 template <uint32_t FEAT>
 static void launch_shade_t(uint32_t blocks, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, const uint32_t* count_in,
-                           uint32_t* count_out, uint32_t* next_work, uint32_t* hz, unsigned long long* counters, bool count,
+                           uint32_t* count_out, uint32_t* hz, unsigned long long* counters, bool count,
                            hipStream_t stream) {
-    if (count) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(blocks), dim3(kShadeThreads), sc.shade_blob_bytes, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
-    else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(blocks), dim3(kShadeThreads), sc.shade_blob_bytes, stream, sc, in, out, rd, count_in, count_out, next_work, hz, counters);
+    if (count) hipLaunchKernelGGL((k_shade<FEAT, true>), dim3(blocks), dim3(kShadeThreads), sc.shade_blob_bytes, stream, sc, in, out, rd, count_in, count_out, hz, counters);
+    else hipLaunchKernelGGL((k_shade<FEAT, false>), dim3(blocks), dim3(kShadeThreads), sc.shade_blob_bytes, stream, sc, in, out, rd, count_in, count_out, hz, counters);
 }
 
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
-                        const uint32_t* count_in, uint32_t* count_out, uint32_t* next_work, uint32_t* hz, unsigned long long* counters, bool count,
+                        const uint32_t* count_in, uint32_t* count_out, uint32_t* hz, unsigned long long* counters, bool count,
                         hipStream_t stream) {
     const uint32_t blocks = rd.q_n * ((max_count + kShadeThreads - 1u) / kShadeThreads);   // max_count = upper bound of the paths in ONE queue
     if (blocks == 0u) return hipSuccess;
     const uint32_t v = pick_variant(cfg.features);
-    if (v == 0u) launch_shade_t<0u>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);
-    else if (v == kVariantMesh) launch_shade_t<kVariantMesh>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);
-    else if (v == kVariantBox) launch_shade_t<kVariantBox>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);
-    else launch_shade_t<F_ALL>(blocks, sc, in, out, rd, count_in, count_out, next_work, hz, counters, count, stream);
+    if (v == 0u) launch_shade_t<0u>(blocks, sc, in, out, rd, count_in, count_out, hz, counters, count, stream);
+    else if (v == kVariantMesh) launch_shade_t<kVariantMesh>(blocks, sc, in, out, rd, count_in, count_out, hz, counters, count, stream);
+    else if (v == kVariantBox) launch_shade_t<kVariantBox>(blocks, sc, in, out, rd, count_in, count_out, hz, counters, count, stream);
+    else launch_shade_t<F_ALL>(blocks, sc, in, out, rd, count_in, count_out, hz, counters, count, stream);
     return hipGetLastError();
 }
 
-hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_init, uint32_t* next_work, uint32_t* out_count, hipStream_t stream) {
+hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_init, uint32_t* out_count, hipStream_t stream) {
     const uint32_t blocks = (n_init + kShadeThreads - 1u) / kShadeThreads;
     if (blocks == 0u) return hipSuccess;
-    hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(kShadeThreads), 0, stream, pool, rd, n_init, next_work, out_count);
+    hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(kShadeThreads), 0, stream, pool, rd, n_init, out_count);
     return hipGetLastError();
 }
 

@@ -665,6 +665,10 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
             while (P > (1u << 20) && (size_t)P * slot_bytes > budget) P >>= 1;
         }
     }
+    // Every slot of the first fill owns a LINEAGE of work items — w, w + P, w + 2P, ... — which its path works through one after the other
+    // (kernels.h RenderDev::lineage). So that all lineages are equally long (and the pool stays full until the last generation), P is
+    // not the cap itself but total / k for the smallest k that fits the cap: 480 M items under a cap of 2^28 run as 2 x 240 M.
+    if (!prm->pool_slots && P < total_items) { const uint64_t k = (total_items + P - 1u) / P; P = (uint32_t)((total_items + k - 1u) / k); }
     // kQueues queues of queue_cap slots, filled 512 at a time in turn (k_generate): P is a multiple of 512 * kQueues
     constexpr uint32_t kGrain = 512u * rtk::kQueues;
     P = std::max<uint32_t>(kGrain, (uint32_t)std::min<uint64_t>(((uint64_t)P + kGrain - 1u) / kGrain * kGrain, 0xFFFFF000ull));
@@ -690,7 +694,6 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     static_assert(rtk::kQStride * sizeof(uint32_t) == kLine, "queue counters are one line apart");
     HIP_TRY(ctx, ctx->counters.ensure(4 * kQ * kLine + sizeof(unsigned long long) * 16));
     char* cbase = (char*)ctx->counters.p;
-    uint32_t* c_next_work = (uint32_t*)(cbase + 0 * kQ * kLine);
     uint32_t* c_head = (uint32_t*)(cbase + 1 * kQ * kLine);
     uint32_t* c_count[2] = {(uint32_t*)(cbase + 2 * kQ * kLine), (uint32_t*)(cbase + 3 * kQ * kLine)};
     unsigned long long* c64 = (unsigned long long*)(cbase + 4 * kQ * kLine);
@@ -714,9 +717,9 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) HIP_TRY(ctx, next_event(e0));
     const uint32_t n_init = (uint32_t)std::min<uint64_t>(P, total_items);
-    rd.n_init = n_init;
+    rd.n_init = n_init; rd.lineage = P;
     rd.q_lo = 0u; rd.q_n = rtk::kQueues; rd.q_shift = 3u;
-    HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, n_init, c_next_work, c_count[0], ctx->stream));
+    HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, n_init, c_count[0], ctx->stream));
     if (timing) { HIP_TRY(ctx, next_event(e1)); spans.push_back({e0, e1, 2}); }
     // The host never waits for an iteration it has just enqueued: the kernels read the pool size from device memory and size-check
     // themselves, so the host only needs (a) an UPPER BOUND of the pool size to size k_shade's grid and (b) to learn that it has
@@ -783,7 +786,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         if ((uint64_t)L.live * rtk::kQueues <= drain_at) {
             hipEvent_t ea = nullptr, eb = nullptr;
             if (timing) HIP_TRY(ctx, next_event_on(ea, L.st));
-            LAUNCH_TRY(rtk::launch_drain(cfg, scene->dev, pd[L.cur], r, L.live, c_count[L.cur], c_head, c_count[1 - L.cur], c_next_work, c64, counting, L.st));
+            LAUNCH_TRY(rtk::launch_drain(cfg, scene->dev, pd[L.cur], r, L.live, c_count[L.cur], c_head, c_count[1 - L.cur], c64, counting, L.st));
             if (timing) { HIP_TRY(ctx, next_event_on(eb, L.st)); spans.push_back({ea, eb, 3}); }
             L.drained = L.live * L.q_n;
             L.done = true;
@@ -796,7 +799,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         LAUNCH_TRY(rtk::launch_extend(cfg, scene->dev, pd[L.cur], r, c_count[L.cur], c_head, c_count[1 - L.cur], c64, counting, L.st));
         if (timing || overlap) HIP_TRY(ctx, next_event_on(eb, L.st));
         if (overlap) last_extend = eb;
-        HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[L.cur], pd[1 - L.cur], r, L.live, c_count[L.cur], c_count[1 - L.cur], c_next_work, c_head, c64, counting, L.st));
+        HIP_TRY(ctx, rtk::launch_shade(cfg, scene->dev, pd[L.cur], pd[1 - L.cur], r, L.live, c_count[L.cur], c_count[1 - L.cur], c_head, c64, counting, L.st));
         if (timing) { HIP_TRY(ctx, next_event_on(ec, L.st)); spans.push_back({ea, eb, 0}); spans.push_back({eb, ec, 1}); if (lane_index == 0u) iter_live.push_back(L.live); }
         L.cur = 1 - L.cur;
         const uint32_t ring = (L.launched % kRing) + lane_index * kRing;

@@ -4,10 +4,10 @@
 #include "../ray-tracer-archive_amd/csrc/kernels.h"
 namespace rtk {
 const char* launch_note() { return "asan host build: no kernels"; }
-hipError_t launch_generate(const PoolDev&, const RenderDev&, uint32_t, uint32_t*, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_generate(const PoolDev&, const RenderDev&, uint32_t, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_extend(const LaunchCfg&, const SceneDev&, const PoolDev&, const RenderDev&, const uint32_t*, uint32_t*, uint32_t*, unsigned long long*, bool, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_drain(const LaunchCfg&, const SceneDev&, const PoolDev&, const RenderDev&, uint32_t, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, unsigned long long*, bool, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_shade(const LaunchCfg&, const SceneDev&, const PoolDev&, const PoolDev&, const RenderDev&, uint32_t, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, unsigned long long*, bool, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_drain(const LaunchCfg&, const SceneDev&, const PoolDev&, const RenderDev&, uint32_t, const uint32_t*, uint32_t*, uint32_t*, unsigned long long*, bool, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_shade(const LaunchCfg&, const SceneDev&, const PoolDev&, const PoolDev&, const RenderDev&, uint32_t, const uint32_t*, uint32_t*, uint32_t*, unsigned long long*, bool, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_resolve(const RenderDev&, float*, uint32_t, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_write_color(const float*, uint32_t, uint32_t, uint8_t*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_untile_f32(const float*, float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t, hipStream_t) { return hipErrorNotSupported; }
