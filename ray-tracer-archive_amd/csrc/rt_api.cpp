@@ -688,7 +688,8 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `prefix` is a stack vector
     rd.tile_prefix = (const uint32_t*)ctx->tile_prefix.p;
     // counters, one 128-byte line each (they are hit by atomics from every workgroup):
-    // line 0 next_work, line 1 queue head, lines 2,3 pool counts; 64-bit statistics from line 4
+    // line 0 unused since round 3 (it held the queues' next-work-item counters; a path now finds its next item by itself, kernels.h RenderDev::lineage),
+    // line 1 queue head, lines 2,3 pool counts; 64-bit statistics from line 4
     // (four counters per queue: next work item, queue head, size of either pool; each on a line of its own)
     constexpr size_t kLine = 128, kQ = rtk::kQueues;
     static_assert(rtk::kQStride * sizeof(uint32_t) == kLine, "queue counters are one line apart");
