@@ -235,6 +235,8 @@ DEVI int sphere_fast(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax,
     if (delta < -4.f * kEps * (lp2 + l2)) return 0;                         // the line passes outside, beyond any rounding
     // error of delta ~ 6 eps sqrt(lp2 l2) (+ 2 eps lp2); half chord h = sqrt(delta / a): dh = E / (2 sqrt(a delta)) < tol
     //   <=>  E^2 < 4 tol^2 a delta,  E^2 <= 54 eps^2 lp2 l2 with the small term folded in
+    // (a tolerance that grows with the sphere's distance — 4e-7 |oc| — keeps the cluster spheres of the book-2 final scene, 500 units out,
+    // on this f32 path instead of the f64 one: measured, no gain — k_extend 84.1 against 84.4 ms — so the absolute tolerance stays)
     constexpr float k1 = 54.f * kEps * kEps / (4.f * RT_SPHERE_TOL * RT_SPHERE_TOL);
     const float ad = a * delta;
     if (!(k1 * lp2 * l2 < ad)) return 2;                                    // also delta <= 0 within its error, NaN
@@ -487,7 +489,10 @@ DEVI void set_slab_ray(V3 o, V3 d, SlabRay& r) {
 #define RT_CHUNK 1024       // rays a wave takes from the queue head per atomic (2^28 rays per launch: same-address atomics cost ~11 ns each)
 #endif
 #ifndef RT_STEPS
-#define RT_STEPS 3          // node visits between two looks at the leaf batch / the refill (measured: 2: 63.9 ms, 3: 59.7, 4: 60.9, 6: 60.8, 8: 65.4)
+#define RT_STEPS 3          // node visits between two looks at the leaf batch / the refill (book-1, round 3: 2: 56.6 ms, 3: 52.5, 4: 53.3)
+#endif
+#ifndef RT_STEPS_ALL
+#define RT_STEPS_ALL 4      // ... in the all-features variant, whose looks are dearer (media, wrappers, five kinds): book-2 final 2: 96.4 ms, 3: 88.7, 4: 84.6
 #endif
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 24    // lanes with a pending leaf that trigger a primitive-test pass
@@ -501,7 +506,7 @@ DEVI void set_slab_ray(V3 o, V3 d, SlabRay& r) {
 constexpr int kRefillMin = RT_REFILL_MIN;
 constexpr uint32_t kExtendThreads = RT_EXTEND_THREADS;
 constexpr uint32_t kChunk = RT_CHUNK;
-constexpr int kSteps = RT_STEPS;
+constexpr int kStepsPlain = RT_STEPS, kStepsAll = RT_STEPS_ALL;
 constexpr int kLeafBatch = RT_LEAF_BATCH;
 
 // Lane-level state machine. A lane's whole traversal state is the ADDRESS of the record it visits next (device_types.h NodeDev,
@@ -563,6 +568,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                                                  unsigned long long* __restrict__ counters, RenderDev rd) {
     extern __shared__ float4 lds[];
     constexpr bool LDS = MODE == M_LDS, TOP = MODE == M_TOP, C16 = MODE == M_C16;
+    constexpr int kSteps = FEAT == F_ALL ? kStepsAll : kStepsPlain;
     // The pool is kQueues independent queues (kernels.h): a wave serves the queue of its number mod kQueues, a DRAIN workgroup the
     // queue of its block number; every counter exists once per queue, 128 bytes apart.
     if (blockIdx.x == 0 && threadIdx.x < rd.q_n) count_out_to_zero[(rd.q_lo + threadIdx.x) * kQStride] = 0u;   // the next k_shade appends to them
@@ -844,10 +850,18 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             // Aabb::hit (aabb.rs:31-55, interval carried across axes), on (centre, half extent): 4 packed ops for x and y,
             // one packed FMA + add/sub for z. min3/max3 ignore a NaN operand (0*inf), which keeps the box — conservative,
             // like the reference. A record without a box has h = inf; a self-loop record has h < 0 and both links on itself.
+#ifdef RT_PLAIN_VISIT
+            // the same arithmetic in plain v_fma_f32 / v_add_f32 (A/B against the packed form: VERDICT round 2, next #5)
+            const F2 tc = F2{fmaf(n0.x, sr.inv_xy.x, sr.noi_xy.x), fmaf(n0.y, sr.inv_xy.y, sr.noi_xy.y)};
+            const F2 th = F2{fmaf(n0.z, sr.ainv_xy.x, sr.e_xy.x), fmaf(n0.w, sr.ainv_xy.y, sr.e_xy.y)};
+            const F2 tz = F2{fmaf(n1.x, sr.inv_z.x, sr.noi_z.x), fmaf(n1.y, sr.inv_z.y, sr.noi_z.y)};
+            const F2 lo = F2{tc.x - th.x, tc.y - th.y}, hi = F2{tc.x + th.x, tc.y + th.y};
+#else
             const F2 tc = __builtin_elementwise_fma(F2{n0.x, n0.y}, sr.inv_xy, sr.noi_xy);   // (tcx, tcy)
             const F2 th = __builtin_elementwise_fma(F2{n0.z, n0.w}, sr.ainv_xy, sr.e_xy);      // (thx, thy), widened by the ray's own rounding
             const F2 tz = __builtin_elementwise_fma(F2{n1.x, n1.y}, sr.inv_z, sr.noi_z);      // (tcz, thz)
             const F2 lo = tc - th, hi = tc + th;
+#endif
             const float tnear = fmaxf(fmaxf(lo.x, lo.y), fmaxf(tz.x - tz.y, kTMin));
             const float tfar = fminf(fminf(hi.x, hi.y), fminf(tz.x + tz.y, tmax));
             if (COUNT) c_nodes += (node < special && n0.z < kInf) ? 1ull : 0ull;
