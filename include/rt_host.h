@@ -3,7 +3,7 @@
  *
  * These are NOT part of the GPU hot path: they are the host code the reference keeps on its side of
  * the boundary — scene functions (main.rs:171-649), Camera::new (camera.rs:21-59), write_color
- * (main.rs:141-169), image encode (main.rs:791-796, PNG here instead of JPEG) — exported with a C
+ * (main.rs:141-169), image encode (main.rs:791-796: JPEG at quality 100 into output/book3/imageNN.jpg; PNG as well) — exported with a C
  * ABI so that non-C++ callers (the Python tests and bench, a Rust binding) can use them.
  */
 #ifndef RT_HOST_H
@@ -41,6 +41,12 @@ int rt_host_tonemap(const float* rgb_sum, uint32_t width, uint32_t height, uint3
 /* RGB8 -> PNG file (zlib). Returns 0, or -1 if the file cannot be written (the reference prints
  * and continues on an encode failure, main.rs:793-796). */
 int rt_host_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+/* RGB8 -> baseline JPEG (JFIF, YCbCr 4:4:4, the standard's Huffman tables; host/jpeg_writer.hpp). quality 1..100: the reference
+ * writes its frame with `ImageOutputFormat::Jpeg(quality)`, quality = 100 (main.rs:721,793). Returns 0 / -1 like rt_host_write_png. */
+int rt_host_write_jpeg(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height, int quality);
+/* What main.rs:653-656 + 791-796 do with `path`: create its parent directories ("output/book3/"), then encode by extension
+ * (.jpg / .jpeg / .png). */
+int rt_host_write_image(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height, int quality);
 
 #ifdef __cplusplus
 }

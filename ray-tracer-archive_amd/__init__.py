@@ -6,7 +6,7 @@ a ``Context`` does, and fails loudly when the HIP library or a device is missing
 fallback in the product path.
 """
 from . import _abi  # noqa: F401
-from .api import (Context, Scene, HostScene, RtError, camera_new, lib, lib_path, tonemap, write_color, write_png, untile,
+from .api import (Context, Scene, HostScene, RtError, camera_new, lib, lib_path, tonemap, write_color, write_png, write_image, untile,
                   output_floats, make_params, compile_info, compile_dump, MultiContext, MultiScene, comm_unique_id, untile_rgb8, wide_layout_check, runtime_libraries, upload_options)  # noqa: F401
 from .scene import SceneBuilder  # noqa: F401
 from .scene_json import JsonScene, load_scene  # noqa: F401

@@ -115,7 +115,7 @@ RT_HIP_SYMBOLS = ["rt_ctx_create", "rt_ctx_destroy", "rt_scene_upload", "rt_scen
                   "rt_render_gather", "rt_untile_rgb8", "rt_untile_device", "rt_scene_top_layout_check", "rt_scene_upload_ex", "rt_scene_upload_multi_ex",
                   "rt_runtime_libraries", "rt_test_fail_next_renders", "rt_scene_compile_info_ex", "rt_scene_compile_dump_ex", "rt_scene_wide_layout_check"]
 RT_HOST_SYMBOLS = ["rt_host_scene_create", "rt_host_scene_desc", "rt_host_scene_camera", "rt_host_scene_destroy", "rt_host_camera_new",
-                   "rt_host_write_color", "rt_host_tonemap", "rt_host_write_png"]
+                   "rt_host_write_color", "rt_host_tonemap", "rt_host_write_png", "rt_host_write_jpeg", "rt_host_write_image"]
 
 
 def declare(lib):
@@ -206,4 +206,8 @@ def declare(lib):
     lib.rt_host_tonemap.argtypes = [P(C.c_float), u32, u32, u32, P(C.c_uint8)]
     lib.rt_host_write_png.restype = i32
     lib.rt_host_write_png.argtypes = [C.c_char_p, P(C.c_uint8), u32, u32]
+    lib.rt_host_write_jpeg.restype = i32
+    lib.rt_host_write_jpeg.argtypes = [C.c_char_p, P(C.c_uint8), u32, u32, i32]
+    lib.rt_host_write_image.restype = i32
+    lib.rt_host_write_image.argtypes = [C.c_char_p, P(C.c_uint8), u32, u32, i32]
     return lib

@@ -84,6 +84,14 @@ def write_png(path, rgb8):
     return lib().rt_host_write_png(str(path).encode(), rgb8.ctypes.data_as(C.POINTER(C.c_uint8)), w, h)
 
 
+def write_image(path, rgb8, quality=100):
+    """rt_host_write_image: creates the parent directories and encodes by extension (.jpg at `quality` — the reference's
+    output/book3/image12.jpg, main.rs:653-656,791-796 — or .png)."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = rgb8.shape
+    return lib().rt_host_write_image(str(path).encode(), rgb8.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, quality)
+
+
 def untile(params, gathered):
     gathered = np.ascontiguousarray(gathered, dtype=np.float32)
     out = np.zeros((params.height, params.width, 3), dtype=np.float32)

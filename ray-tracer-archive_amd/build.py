@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librt_hip.so")
 SOURCES = ["csrc/kernels.hip", "csrc/rt_api.cpp", "csrc/rt_multi.cpp", "csrc/scene_compile.cpp", "csrc/wide_bvh.cpp", "host/host_capi.cpp"]
-HEADERS = ["csrc/kernels.h", "csrc/device_types.h", "csrc/rt_internal.hpp", "csrc/scene_compile.hpp", "csrc/wide_bvh.hpp", "host/rt_host.hpp", "../include/rt_hip.h", "../include/rt_host.h"]
+HEADERS = ["csrc/kernels.h", "csrc/device_types.h", "csrc/rt_internal.hpp", "csrc/scene_compile.hpp", "csrc/wide_bvh.hpp", "host/rt_host.hpp", "host/jpeg_writer.hpp", "../include/rt_hip.h", "../include/rt_host.h"]
 # -ffp-contract=off: a float expression means the same IEEE operations wherever it is inlined, so a
 # sample's radiance does not depend on which kernel / call site generated its camera ray (and the
 # device evaluates the reference's expressions in the order written). Hot loops spell out fmaf/fma.

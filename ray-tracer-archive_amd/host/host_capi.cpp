@@ -1,9 +1,13 @@
 // host_capi.cpp — C exports of the host mirror (include/rt_host.h). No GPU code.
 #include "../../include/rt_host.h"
 #include "rt_host.hpp"
+#include "jpeg_writer.hpp"
+
+#include <sys/stat.h>
 
 #include <zlib.h>
 
+#include <cctype>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -100,6 +104,29 @@ int rt_host_write_png(const char* path, const uint8_t* rgb8, uint32_t w, uint32_
     const size_t wr = std::fwrite(png.data(), 1, png.size(), f);
     std::fclose(f);
     return wr == png.size() ? 0 : -1;
+}
+
+int rt_host_write_jpeg(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h, int quality) {
+    if (!path || !rgb8 || !w || !h || w > 65535u || h > 65535u) return -1;
+    const std::vector<uint8_t> jpg = rtjpeg::encode(rgb8, w, h, quality);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return -1;
+    const size_t wr = std::fwrite(jpg.data(), 1, jpg.size(), f);
+    std::fclose(f);
+    return wr == jpg.size() ? 0 : -1;
+}
+
+int rt_host_write_image(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h, int quality) {
+    if (!path) return -1;
+    // main.rs:653-656: `create_dir_all(path.parent())` before anything is rendered into "output/book3/image12.jpg"
+    std::string p(path);
+    for (size_t i = 1; i < p.size(); ++i) if (p[i] == '/') { const std::string dir = p.substr(0, i); (void)mkdir(dir.c_str(), 0777); }
+    const size_t dot = p.rfind('.');
+    std::string ext = dot == std::string::npos ? "" : p.substr(dot + 1);
+    for (char& ch : ext) ch = (char)std::tolower((unsigned char)ch);
+    if (ext == "jpg" || ext == "jpeg") return rt_host_write_jpeg(path, rgb8, w, h, quality);
+    if (ext == "png") return rt_host_write_png(path, rgb8, w, h);
+    return -1;
 }
 
 }  // extern "C"

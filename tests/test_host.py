@@ -97,6 +97,30 @@ def test_png_writer_roundtrip(pkg, tmp_path):
     assert pkg.write_png(tmp_path / "no_such_dir" / "a.png", img) == -1            # encode failure is reported, not fatal (main.rs:793-796)
 
 
+def test_jpeg_writer_and_output_layout(pkg, tmp_path):
+    """The reference writes its frame as JPEG, quality 100, into output/book3/image12.jpg after creating the directories
+    (main.rs:653-656, 721, 791-796). rt_host_write_image does both; the file is a baseline JFIF any decoder reads (PIL here), and at
+    quality 100 without chroma subsampling it is the picture to within +-2 of 255 (a gradient, noise, and a frame smaller than a block)."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    y, x = np.mgrid[0:150, 0:203]
+    grad = np.stack([(x * 255 // 202), (y * 255 // 149), ((x + y) * 255 // 351)], axis=2).astype(np.uint8)
+    noise = rng.integers(0, 256, size=(64, 48, 3), dtype=np.uint8)
+    tiny = rng.integers(0, 256, size=(5, 3, 3), dtype=np.uint8)
+    for name, img, tol in (("grad", grad, 2), ("tiny", tiny, 3), ("noise", noise, 3)):
+        path = tmp_path / "output" / "book3" / (name + ".jpg")
+        assert pkg.write_image(path, img, 100) == 0
+        back = np.asarray(Image.open(path).convert("RGB"))
+        assert back.shape == img.shape
+        assert np.abs(back.astype(int) - img.astype(int)).max() <= tol, (name, np.abs(back.astype(int) - img.astype(int)).max())
+        assert open(path, "rb").read(4)[:2] == b"\xff\xd8" and Image.open(path).format == "JPEG"
+    lo = tmp_path / "output" / "book3" / "q50.jpg"
+    assert pkg.write_image(lo, grad, 50) == 0 and lo.stat().st_size < (tmp_path / "output" / "book3" / "grad.jpg").stat().st_size
+    assert np.abs(np.asarray(Image.open(lo).convert("RGB")).astype(int) - grad.astype(int)).mean() < 3.0
+    assert pkg.write_image(tmp_path / "a" / "b.png", grad) == 0 and np.array_equal(np.asarray(Image.open(tmp_path / "a" / "b.png")), grad)
+    assert pkg.write_image(tmp_path / "c.bmp", grad) == -1
+
+
 def test_tonemap_is_write_color(pkg):
     rng = np.random.default_rng(2)
     s = rng.uniform(0, 40, size=(5, 7, 3)).astype(np.float32)
