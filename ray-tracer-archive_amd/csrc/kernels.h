@@ -65,7 +65,12 @@ struct SceneDev {
 // The pool is kQueues independent queues of queue_cap slots each (slot s of queue q = record q * queue_cap + s): paths stay in
 // their queue for life, every counter (pool size, queue head, next work item) exists once per queue, kQStride u32 = 128 bytes apart.
 // One counter pair for the whole pool made k_shade wait on same-address atomics (one per 512 paths, ~11 ns each: 29 ms of 39).
-constexpr uint32_t kQueues = 8, kQStride = 32;
+#ifndef RT_QUEUES
+#define RT_QUEUES 8       // tuning builds: 16, 32, 64 (more counters for k_shade's atomics, fewer waves per queue in k_extend: 32 cost k_extend 4 ms of 52)
+#endif
+constexpr uint32_t kQueues = RT_QUEUES, kQStride = 32;
+constexpr uint32_t kQShift = kQueues == 8 ? 3u : kQueues == 16 ? 4u : kQueues == 32 ? 5u : kQueues == 64 ? 6u : 0u;
+static_assert(kQShift != 0u && (1u << kQShift) == kQueues, "kQueues: 8, 16, 32 or 64");
 struct PoolDev {
     rtd::Float4* ray_o; rtd::Float4* ray_d; uint2* hit;
     rtd::Float4* s0; uint32_t* sd; rtd::Float4* s1;

@@ -550,6 +550,9 @@ struct PathState {
     V3 T, acc;
     uint32_t work, sample;       // the ITEM ID (item_id above, not the work item number) and the index of its sample in flight
     uint32_t from;               // primitive id the ray starts on (hit-record id), 0 = none
+#ifdef RT_SHADE_STAMPS
+    unsigned long long st_prim, st_mat;   // s_memtime when the primitive's record / the material's record had arrived
+#endif
 };
 // The RNG of the path that renders `sample` of the pixel of work item `work`, after `n` draws (rt_weekend.rs:8-19's stream, DESIGN "RNG contract")
 // `sample`: out — the stored index for a multi-sample item (with_acc), else the item's own block number (one sample per item)
@@ -1383,6 +1386,10 @@ DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const P
 #define RT_SHADE_THREADS 512
 #endif
 constexpr uint32_t kShadeThreads = RT_SHADE_THREADS;
+#ifndef RT_SHADE_WAVE_ALLOC
+#define RT_SHADE_WAVE_ALLOC 0     // tuning builds (with RT_QUEUES >= 32): every wave allocates for itself — measured, no gain
+#endif
+constexpr bool kShadeWaveAlloc = RT_SHADE_WAVE_ALLOC != 0;
 DEVI uint32_t block_alloc(bool flag, uint32_t* counter, uint32_t* s_scan) {
     const uint32_t wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint64_t m = __ballot(flag);
@@ -1665,8 +1672,14 @@ DEVI uint32_t shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& 
                 }
             }
         }
+#ifdef RT_SHADE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); s.st_prim = __builtin_amdgcn_s_memtime();
+#endif
         const uint32_t mat = meta & rtd::META_MAT_MASK;
         const Float4 ma = sc.mat_a[mat]; const uint32_t mb = sc.mat_b[mat];
+#ifdef RT_SHADE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); s.st_mat = __builtin_amdgcn_s_memtime();
+#endif
         const uint32_t kind = mb & 15u, tex = mb >> 4;
         // the next ray starts on this primitive (not for a medium: its hit point is inside the volume; not for a
         // Metal bounce off a moving sphere: Metal resets the ray's time to 0, which moves the sphere)
@@ -1779,6 +1792,13 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     __shared__ uint32_t s_scan[kShadeThreads / 64 + 1];
     __shared__ uint32_t s_bins[kSortBins + 2];
     extern __shared__ float4 s_tables[];
+#ifdef RT_SHADE_STAMPS
+    // (tuning builds, scripts/gpu_shade_stamps.py) where a wave of k_shade spends its life: every stamp waits for what is in flight
+    unsigned long long sst[6]; sst[0] = __builtin_amdgcn_s_memtime();
+#define SSTAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); sst[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SSTAMP(k)
+#endif
     // the scene's small tables, staged once per workgroup (LDS-DMA, linear copy): shade_segment then follows its chain of dependent
     // look-ups through LDS. The pointers become generic pointers into LDS (flat loads), the code that uses them does not change.
     if (sc.shade_blob_bytes != 0u) {
@@ -1822,6 +1842,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
             if (any) atomicAdd(&counters[CTR_ITERATIONS], 1ull);
         }
     }
+    SSTAMP(1);
     bool alive = i < count_in;
     const bool with_acc = rd.block_shift != 0u;
     PathState s{}; V3 o = v3(0, 0, 0), d = v3(0, 0, 1); float tm = 0.f;
@@ -1835,6 +1856,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
         uint32_t stored = 0u;
         if (with_acc) { const Float4 s1 = in.s1[qbase + i]; s.acc = v3(s1.x, s1.y, s1.z); stored = __float_as_uint(s1.w); }   // else acc = 0: the item is this one sample
         V3 L = v3(0.f, 0.f, 0.f);          // radiance of this sample: set by the terminal event only
+        SSTAMP(2);
         depth = sd & 0xFFu;
         g = path_rng(rd, s.work, with_acc, stored, sd >> 8, s.sample);     // the stream is a function of (pixel, sample): only the draw count travels
         const uint32_t sh = shade_segment<FEAT>(sc, rd, o, d, tm, s, g, depth, hit, L, c_light_rect, c_light_sphere);
@@ -1858,6 +1880,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     }
 
     // ---- compaction: survivors go to the other pool densely (wave64 ballot + prefix, LDS scan across waves) ----
+    SSTAMP(3);
     {
         uint32_t dst;
         if (sc.sort_rays != 0u) {
@@ -1868,9 +1891,27 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
             const uint32_t cy = (uint32_t)fminf(fmaxf((o.y - sc.grid_lo[1]) * fast_rcp(sc.grid_scale[1]) * k4, 0.f), 3.f);
             const uint32_t cz = (uint32_t)fminf(fmaxf((o.z - sc.grid_lo[2]) * fast_rcp(sc.grid_scale[2]) * k4, 0.f), 3.f);
             dst = block_alloc_sorted(alive, alive ? ((oct << 6) | (cz << 4) | (cy << 2) | cx) : 0u, count_out, s_bins);
+        } else if (kShadeWaveAlloc) {
+            // every wave takes its survivors' slots by itself: no barrier, no wave waiting for the slowest of its workgroup. One returning
+            // atomic per wave is eight times the atomics of one per workgroup: needs RT_QUEUES = 32 counters or more
+            const uint64_t m = __ballot(alive);
+            uint32_t base = 0u;
+            if ((threadIdx.x & 63u) == 0u && m != 0ull) base = atomicAdd(count_out, (uint32_t)__popcll(m));
+            dst = first_lane_u32(base) + lane_rank(m);
         } else dst = block_alloc(alive, count_out, s_scan);
+        SSTAMP(4);
         if (alive) store_path(out, qbase + dst, o, d, tm, s, g.n, depth, with_acc);
     }
+#ifdef RT_SHADE_STAMPS
+    SSTAMP(5);
+    if ((threadIdx.x & 63u) == 0u && (i >> 6) * 64u < count_in && ((blockIdx.x >> rd.q_shift) & 63u) == 0u) {   // one workgroup in 64 reports: same-address atomics
+        if (i + 64u > count_in || !alive) sst[2] = sst[1];            // (a wave whose first lane holds no path made no record stamp)
+        for (int k = 0; k < 5; ++k) atomicAdd(&counters[CTR_PRIM_TESTS + k], sst[k + 1] - sst[k]);
+        atomicAdd(&counters[CTR_NODE_TESTS], 1ull);
+        // the first lane's path, if it hit something: records -> primitive record -> material record (of the shade_segment share)
+        if (s.st_prim != 0ull) { atomicAdd(&counters[CTR_DEBUG + 0], s.st_prim - sst[2]); atomicAdd(&counters[CTR_DEBUG + 1], s.st_mat - s.st_prim); atomicAdd(&counters[CTR_DEBUG + 2], 1ull); }
+    }
+#endif
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { c_samples += __shfl_down(c_samples, off); c_light_rect += __shfl_down(c_light_rect, off); c_light_sphere += __shfl_down(c_light_sphere, off); }
         if ((threadIdx.x & 63u) == 0u) {
@@ -2050,7 +2091,8 @@ static hipError_t launch_extend_wide_c(const LaunchCfg& cfg, const SceneDev& sc,
     if (cfg.extend_geometry) { cfg.extend_geometry[0] = 256u; cfg.extend_geometry[1] = (uint32_t)per_cu; }
     // a wave holds 8 rays: the resident set, or as many groups as the queue can feed (32 rays per 256-thread group at a time)
     uint32_t groups = std::min<uint32_t>(cfg.n_cu * (uint32_t)per_cu, std::max<uint32_t>(1u, (cfg.max_rays + 31u) / 32u));
-    groups = (groups + 1u) / 2u * 2u;                              // 4 waves a group: a multiple of kQueues waves
+    const uint32_t gq = std::max<uint32_t>(1u, rd.q_n * 64u / 256u);   // 4 waves a group: a multiple of q_n waves
+    groups = (groups + gq - 1u) / gq * gq;
     hipLaunchKernelGGL((k_extend_wide<FEAT, COUNT>), dim3(groups), dim3(256), 0, stream, sc, pool, count_ptr, head, cz, counters, rd);
     return hipGetLastError();
 }

@@ -719,7 +719,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     if (timing) HIP_TRY(ctx, next_event(e0));
     const uint32_t n_init = (uint32_t)std::min<uint64_t>(P, total_items);
     rd.n_init = n_init; rd.lineage = P;
-    rd.q_lo = 0u; rd.q_n = rtk::kQueues; rd.q_shift = 3u;
+    rd.q_lo = 0u; rd.q_n = rtk::kQueues; rd.q_shift = rtk::kQShift;
     HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, n_init, c_count[0], ctx->stream));
     if (timing) { HIP_TRY(ctx, next_event(e1)); spans.push_back({e0, e1, 2}); }
     // The host never waits for an iteration it has just enqueued: the kernels read the pool size from device memory and size-check
@@ -763,7 +763,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     Lane lanes[2];
     // upper bound of the size of the LARGEST queue from here on (a queue never grows): it sizes the grids, and 0 ends the render
     const uint32_t live0 = std::min<uint32_t>(rd.queue_cap, (n_init + rtk::kQueues - 1u) / rtk::kQueues + 512u);
-    for (uint32_t l = 0; l < n_lanes; ++l) lanes[l] = Lane{l == 0 ? ctx->stream : ctx->stream2, l * per_lane, per_lane, per_lane == 8u ? 3u : 2u, live0, 0, 0u, 0u, false, {}, 0};
+    for (uint32_t l = 0; l < n_lanes; ++l) lanes[l] = Lane{l == 0 ? ctx->stream : ctx->stream2, l * per_lane, per_lane, rtk::kQShift - (overlap ? 1u : 0u), live0, 0, 0u, 0u, false, {}, 0};
     if (overlap) {   // the second stream starts behind k_generate
         hipEvent_t eg = nullptr; HIP_TRY(ctx, next_event(eg));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, eg, 0));
@@ -846,7 +846,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         }
         stats->samples = valid_pixels * rd.spp;
         stats->segments = ctx->h_counters[rtk::CTR_SEGMENTS];
-#ifdef RT_STAMPS
+#if defined(RT_STAMPS) || defined(RT_SHADE_STAMPS)
         const bool copy_counts = true;    // k_extend's pass statistics travel in these slots (scripts/gpu_stamps.py)
 #else
         const bool copy_counts = counting;
