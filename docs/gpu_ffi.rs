@@ -201,6 +201,7 @@ extern "C" {
     // ---- the process's ROCm runtime libraries (refuses two HIP runtimes in one process); fault injection for failure-path tests ----
     pub fn rt_runtime_libraries(out: *mut c_char, cap: u64) -> c_int;
     pub fn rt_test_fail_next_renders(ctx: *mut RtCtx, n: u32) -> c_int;
+    pub fn rt_test_device_workers(n_workers: c_int, rounds: c_int) -> c_int;
 
     // ---- scene-compiler introspection (host only) ----
     pub fn rt_scene_compile_info(desc: *const RtSceneDesc, out: *mut RtCompileInfo) -> c_int;

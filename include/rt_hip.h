@@ -261,6 +261,8 @@ enum {
                                             the default binary records on MI355X — VALU-bound at 8 rays per wave, DESIGN.md section 5 — kept as an option) */
     RT_LAYOUT_REFERENCE_COUNTERS = 1u | 4u | 16u
 };
+/* Checked, not dropped: a layout bit this library does not know, a switch set both ways (LISTS_AS_REFERENCE with LISTS_CULLED,
+ * NO_MEMBER_BOXES with MEMBER_BOXES), struct_bytes < 8 or a negative list_park_cost is RT_ERR_INVALID with the reason in rt_last_error. */
 typedef struct RtUploadOptions {
     uint32_t struct_bytes;     /* sizeof(RtUploadOptions) as the caller compiled it (the struct may grow at its end) */
     uint32_t layout_flags;     /* RT_LAYOUT_* */
@@ -383,6 +385,11 @@ int rt_runtime_libraries(char* out, uint64_t cap);
 /* Fault injection for the failure-path tests: the next `n` renders on this context fail with RT_ERR_DEVICE before any kernel is
    launched (n = 0 disarms). Lets a one-GPU box rehearse "one rank of a collective render fails". */
 int rt_test_fail_next_renders(RtCtx* ctx, uint32_t n);
+
+/* Host only (no device is touched): the per-device host threads of a multi-GPU context — started with the context, parked between
+   frames — rehearsed with `n_workers` threads over `rounds` frames of counting jobs; RT_OK when every worker ran exactly once per
+   frame. (rt_render_multi itself needs n > 1 devices; this is what a one-GPU box and the CPU suite can check of it.) */
+int rt_test_device_workers(int n_workers, int rounds);
 
 /* Builds the 8-wide tree a scene in HBM is walked through (a static BVH: spheres, rects, triangles, boxes under box nodes) and checks it
    on the host: every primitive sits in exactly one leaf entry of at most eight members of one kind; every entry's box, decoded with the

@@ -113,7 +113,7 @@ RT_HIP_SYMBOLS = ["rt_ctx_create", "rt_ctx_destroy", "rt_scene_upload", "rt_scen
                   "rt_scene_compile_dump", "rt_ctx_create_multi", "rt_ctx_destroy_multi", "rt_scene_upload_multi", "rt_scene_destroy_multi",
                   "rt_render_multi", "rt_render_multi_rgb8", "rt_last_error_multi", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_selftest",
                   "rt_render_gather", "rt_untile_rgb8", "rt_untile_device", "rt_scene_top_layout_check", "rt_scene_upload_ex", "rt_scene_upload_multi_ex",
-                  "rt_runtime_libraries", "rt_test_fail_next_renders", "rt_scene_compile_info_ex", "rt_scene_compile_dump_ex", "rt_scene_wide_layout_check"]
+                  "rt_runtime_libraries", "rt_test_fail_next_renders", "rt_test_device_workers", "rt_scene_compile_info_ex", "rt_scene_compile_dump_ex", "rt_scene_wide_layout_check"]
 RT_HOST_SYMBOLS = ["rt_host_scene_create", "rt_host_scene_desc", "rt_host_scene_camera", "rt_host_scene_destroy", "rt_host_camera_new",
                    "rt_host_write_color", "rt_host_tonemap", "rt_host_write_png", "rt_host_write_jpeg", "rt_host_write_image"]
 
@@ -140,6 +140,8 @@ def declare(lib):
     lib.rt_runtime_libraries.argtypes = [C.c_char_p, u64]
     lib.rt_test_fail_next_renders.restype = i32
     lib.rt_test_fail_next_renders.argtypes = [vp, u32]
+    lib.rt_test_device_workers.restype = i32
+    lib.rt_test_device_workers.argtypes = [i32, i32]
     lib.rt_scene_destroy.restype = i32
     lib.rt_scene_destroy.argtypes = [vp, vp]
     lib.rt_output_floats.restype = i32

@@ -1794,7 +1794,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     extern __shared__ float4 s_tables[];
 #ifdef RT_SHADE_STAMPS
     // (tuning builds, scripts/gpu_shade_stamps.py) where a wave of k_shade spends its life: every stamp waits for what is in flight
-    unsigned long long sst[6]; sst[0] = __builtin_amdgcn_s_memtime();
+    unsigned long long sst[6], sst_regen = 0; sst[0] = __builtin_amdgcn_s_memtime();
 #define SSTAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); sst[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SSTAMP(k)
@@ -1863,6 +1863,9 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
         const bool finished = (sh & SH_FINISHED) != 0u;
         if (sh & SH_TIME_ZERO) tm = 0.0f;
 
+#ifdef RT_SHADE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); sst_regen = __builtin_amdgcn_s_memtime();
+#endif
         if (finished) {
             // one sample done
             if (COUNT) c_samples++;
@@ -1877,6 +1880,9 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
                 else alive = false;
             }
         }
+#ifdef RT_SHADE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); sst_regen = __builtin_amdgcn_s_memtime() - sst_regen;
+#endif
     }
 
     // ---- compaction: survivors go to the other pool densely (wave64 ballot + prefix, LDS scan across waves) ----
@@ -1908,6 +1914,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
         if (i + 64u > count_in || !alive) sst[2] = sst[1];            // (a wave whose first lane holds no path made no record stamp)
         for (int k = 0; k < 5; ++k) atomicAdd(&counters[CTR_PRIM_TESTS + k], sst[k + 1] - sst[k]);
         atomicAdd(&counters[CTR_NODE_TESTS], 1ull);
+        atomicAdd(&counters[CTR_DEBUG + 3], sst_regen);        // end of a sample + the next camera ray (part of the shade_segment share)
         // the first lane's path, if it hit something: records -> primitive record -> material record (of the shade_segment share)
         if (s.st_prim != 0ull) { atomicAdd(&counters[CTR_DEBUG + 0], s.st_prim - sst[2]); atomicAdd(&counters[CTR_DEBUG + 1], s.st_mat - s.st_prim); atomicAdd(&counters[CTR_DEBUG + 2], 1ull); }
     }

@@ -353,6 +353,23 @@ struct rti::UploadOpts {
     bool lds_scene = true, node16 = true, octant_order = true, shade_lds = true, perlin_lds = true, extend_lds_tables = true, wide_nodes = false;
     uint32_t max_top = 1024u, octant_axes = 0u /* 0 = pick; else 8 | mask */;
 };
+// RtUploadOptions as the ABI promises them: unknown or contradictory switches are refused, not dropped
+static int check_options(const RtUploadOptions* options, std::string& err) {
+    if (options) {
+        // a host built against a newer header must hear that this library does not know a switch, not have it dropped
+        constexpr uint32_t kKnown = RT_LAYOUT_LISTS_AS_REFERENCE | RT_LAYOUT_LISTS_CULLED | RT_LAYOUT_NO_MEMBER_BOXES | RT_LAYOUT_MEMBER_BOXES | RT_LAYOUT_CHILD_ORDER_AS_REFERENCE |
+                                    RT_LAYOUT_SCENE_IN_HBM | RT_LAYOUT_NODES_32B | RT_LAYOUT_NO_SHADE_TABLES_IN_LDS | RT_LAYOUT_NO_EXTEND_TABLES_IN_LDS | RT_LAYOUT_WIDE_NODES;
+        if (options->struct_bytes < 8u || options->struct_bytes > 4096u) { err = "RtUploadOptions.struct_bytes is not set (sizeof(RtUploadOptions))"; return RT_ERR_INVALID; }
+        const uint32_t f = options->layout_flags;
+        if (f & ~kKnown) { err = "RtUploadOptions.layout_flags: unknown bit"; return RT_ERR_INVALID; }
+        if (((f & RT_LAYOUT_LISTS_AS_REFERENCE) && (f & RT_LAYOUT_LISTS_CULLED)) || ((f & RT_LAYOUT_NO_MEMBER_BOXES) && (f & RT_LAYOUT_MEMBER_BOXES))) {
+            err = "RtUploadOptions.layout_flags: a switch is set both ways"; return RT_ERR_INVALID;
+        }
+        if (options->struct_bytes >= 24u && !(options->list_park_cost >= 0.f)) { err = "RtUploadOptions.list_park_cost is negative or NaN"; return RT_ERR_INVALID; }
+    }
+    return RT_OK;
+}
+
 static rti::UploadOpts resolve_options(const RtUploadOptions* o) {
     rti::UploadOpts u;
     if (o && o->struct_bytes >= 8u) {
@@ -406,6 +423,7 @@ void rti::scene_image_free(SceneImage* im) { delete im; }
 
 int rti::scene_image_build(const RtSceneDesc* desc, const RtUploadOptions* options, SceneImage** out, std::string& err) {
     *out = nullptr;
+    { const int ok = check_options(options, err); if (ok != RT_OK) return ok; }
     const UploadOpts opt = resolve_options(options);
     std::unique_ptr<SceneImage> im(new SceneImage());
     rtc::CompiledScene& cs = im->cs;
@@ -893,6 +911,7 @@ int rt_untile_rgb8(const RtParams* p, const uint8_t* gathered, uint8_t* rgb8) { 
 int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out) { return rt_scene_compile_info_ex(desc, nullptr, out); }
 int rt_scene_compile_info_ex(const RtSceneDesc* desc, const RtUploadOptions* options, RtCompileInfo* out) {
     if (!desc || !out) return set_err(nullptr, RT_ERR_INVALID, "null argument");
+    { std::string why; const int ok = check_options(options, why); if (ok != RT_OK) return set_err(nullptr, ok, why); }
     rtc::CompiledScene cs;
     const int rc = rtc::compile_scene(*desc, resolve_options(options).compile, cs);
     if (rc != RT_OK) return set_err(nullptr, rc, "scene: " + cs.error);
@@ -952,6 +971,7 @@ int rt_scene_compile_dump(const RtSceneDesc* desc, void* nodes, uint64_t cap_nod
 int rt_scene_compile_dump_ex(const RtSceneDesc* desc, const RtUploadOptions* options, void* nodes, uint64_t cap_nodes, float* spheres, uint32_t* sphere_meta,
                              uint64_t cap_spheres) {
     if (!desc) return set_err(nullptr, RT_ERR_INVALID, "null argument");
+    { std::string why; const int ok = check_options(options, why); if (ok != RT_OK) return set_err(nullptr, ok, why); }
     rtc::CompiledScene cs;
     const int rc = rtc::compile_scene(*desc, resolve_options(options).compile, cs);
     if (rc != RT_OK) return set_err(nullptr, rc, "scene: " + cs.error);

@@ -13,6 +13,8 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -281,7 +283,57 @@ void rti::comm_release(RtCtx* ctx) {
     if (ctx && ctx->comm) { const Rccl* R = rccl(); if (R) (void)R->CommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; ctx->comm_world = 1; ctx->comm_rank = 0; }
 }
 
+// The host threads of the peer devices (one per device beyond the root), started with the context and parked on a condition variable
+// between frames: a frame hands worker i the job of device i + 1 and waits for all of them. (Round 2 spawned and joined n - 1 threads
+// per frame.)
+class DeviceWorkers {
+  public:
+    void start(int n) {
+        job_.assign((size_t)n, nullptr); seen_.assign((size_t)n, 0);
+        for (int i = 0; i < n; ++i) th_.emplace_back([this, i] { loop(i); });
+    }
+    // hand jobs[i] to worker i (the vector must stay alive until wait() has returned)
+    void post(const std::vector<std::function<void()>>& jobs) {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (size_t i = 0; i < jobs.size() && i < job_.size(); ++i) job_[i] = &jobs[i];
+        pending_ = (int)std::min(jobs.size(), job_.size());
+        ++generation_;
+        cv_job_.notify_all();
+    }
+    // ... and return when every one of them has finished
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [this] { return pending_ == 0; });
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_job_.notify_all();
+        for (auto& t : th_) if (t.joinable()) t.join();
+        th_.clear();
+    }
+    ~DeviceWorkers() { stop(); }
+  private:
+    void loop(int i) {
+        for (;;) {
+            const std::function<void()>* f = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_job_.wait(lk, [&] { return stop_ || (generation_ != seen_[(size_t)i] && job_[(size_t)i] != nullptr); });
+                if (stop_) return;
+                seen_[(size_t)i] = generation_; f = job_[(size_t)i]; job_[(size_t)i] = nullptr;
+            }
+            (*f)();
+            { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) cv_done_.notify_all(); }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_; std::condition_variable cv_job_, cv_done_;
+    std::vector<const std::function<void()>*> job_; std::vector<uint64_t> seen_;
+    uint64_t generation_ = 0; int pending_ = 0; bool stop_ = false;
+};
+
 struct RtMultiCtx {
+    DeviceWorkers workers;
     std::vector<RtCtx*> ctx;
     std::string err;
     void* host_pinned = nullptr; size_t host_pinned_bytes = 0;
@@ -296,6 +348,24 @@ int rt_runtime_libraries(char* out, uint64_t cap) {
     const bool ok = runtime_libraries_ok(listing, why);
     if (out && cap) { const size_t n = std::min<size_t>(listing.size(), (size_t)cap - 1); std::memcpy(out, listing.data(), n); out[n] = 0; }
     return ok ? RT_OK : set_err(nullptr, RT_ERR_DEVICE, why);
+}
+
+int rt_test_device_workers(int n_workers, int rounds) {
+    if (n_workers < 0 || n_workers > 64 || rounds < 0) return set_err(nullptr, RT_ERR_INVALID, "n_workers / rounds");
+    DeviceWorkers w;
+    w.start(n_workers);
+    std::vector<int> ran((size_t)n_workers, 0);
+    int root = 0;
+    for (int r = 0; r < rounds; ++r) {
+        std::vector<std::function<void()>> jobs;
+        for (int i = 0; i < n_workers; ++i) jobs.emplace_back([&ran, i, r] { if (ran[(size_t)i] == r) ++ran[(size_t)i]; });
+        w.post(jobs);
+        ++root;                   // (the calling thread's own part of a frame)
+        w.wait();
+    }
+    w.stop();
+    for (int i = 0; i < n_workers; ++i) if (ran[(size_t)i] != rounds) return set_err(nullptr, RT_ERR_DEVICE, "a worker missed or repeated a frame");
+    return root == rounds ? RT_OK : RT_ERR_DEVICE;
 }
 
 int rt_comm_unique_id(uint8_t* id_out) {
@@ -372,6 +442,7 @@ const char* rt_last_error_multi(const RtMultiCtx* m) { return m ? m->err.c_str()
 
 int rt_ctx_destroy_multi(RtMultiCtx* m) {
     if (!m) return RT_OK;
+    m->workers.stop();
     if (!m->ctx.empty() && m->ctx[0]) { (void)hipSetDevice(m->ctx[0]->device); m->frame.release(); if (m->host_pinned) (void)hipHostFree(m->host_pinned); }
     for (RtCtx* c : m->ctx) rt_ctx_destroy(c);
     delete m;
@@ -399,6 +470,7 @@ int rt_ctx_create_multi(const int* device_ids, int n, RtMultiCtx** out) {
         const int r = attach_comm(m->ctx[i], comms[i], i, n);
         if (r != RT_OK) { const std::string why = m->ctx[i]->err; for (int k = i + 1; k < n; ++k) (void)R->CommDestroy(comms[k]); rt_ctx_destroy_multi(m); return set_err(nullptr, r, why); }
     }
+    m->workers.start(n - 1);
     *out = m;
     return RT_OK;
 }
@@ -447,10 +519,11 @@ static int render_multi(RtMultiCtx* m, const RtMultiScene* s, const RtCamera* ca
     // one host thread per device: each runs its own wavefront loop (it has host round trips) and its side of the exchange
     std::vector<int> rc((size_t)n, RT_OK);
     std::vector<RtStats> st((size_t)n);
-    std::vector<std::thread> th;
-    for (int i = 1; i < n; ++i) th.emplace_back([&, i] { rc[i] = render_gather_rank(m->ctx[i], s->scene[i], cam, prm, kind, nullptr, &st[i]); });
-    rc[0] = render_gather_rank(root, s->scene[0], cam, prm, kind, m->frame.p, &st[0]);
-    for (auto& t : th) t.join();
+    std::vector<std::function<void()>> jobs;
+    for (int i = 1; i < n; ++i) jobs.emplace_back([&, i] { rc[i] = render_gather_rank(m->ctx[i], s->scene[i], cam, prm, kind, nullptr, &st[i]); });
+    m->workers.post(jobs);          // the peers' host threads were started with the context
+    rc[0] = render_gather_rank(root, s->scene[0], cam, prm, kind, m->frame.p, &st[0]);   // the root's part on the calling thread
+    m->workers.wait();
     // the device that failed its own part speaks first (the others only report RT_ERR_PEER, "rank k failed")
     for (int pass = 0; pass < 2; ++pass)
         for (int i = 0; i < n; ++i)

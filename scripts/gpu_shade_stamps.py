@@ -26,5 +26,6 @@ names = ["queue size", "path records", "shade_segment", "compaction", "stores"]
 print(which, "waves", waves, "cycles/wave (100 MHz) %.0f = %.2f us" % (tot / waves, tot / waves / 100.0), "shade_ms %.1f" % st["shade_ms"])
 print("  " + "; ".join("%s %.1f%%" % (n, 100.0 * v / tot) for n, v in zip(names, ph)))
 d = st["debug"]
+print("  end of sample + next camera ray: %.0f cycles a wave (inside the shade_segment share)" % (d[3] / waves))
 if d[2]:
     print("  of shade_segment (waves whose first lane hit a primitive: %d): primitive record %.0f cycles, material record %.0f cycles, whole phase %.0f" % (d[2], d[0] / d[2], d[1] / d[2], ph[2] / waves))

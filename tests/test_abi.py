@@ -109,3 +109,32 @@ def test_rust_shim_covers_the_header():
         assert re.search(r"pub const %s: i32" % kind, rs), kind
     for used in set(re.findall(r"\bRT_[A-Z_0-9]*[A-Z0-9]\b", fl)):     # not the "RT_HIT_*" of the comments
         assert re.search(r"pub const %s\b" % used, rs), used + " is used by scene_flatten.rs but not declared in gpu_ffi.rs"
+
+
+def test_upload_options_are_checked_not_dropped(pkg):
+    """RtUploadOptions (include/rt_hip.h): an unknown layout bit, a switch set both ways, an unset struct_bytes or a negative park cost is
+    RT_ERR_INVALID with a reason — on the host-only compile entry points here, by the same check rt_scene_upload_ex makes."""
+    A, lib = pkg._abi, pkg.lib()
+    hs = pkg.HostScene("book1", 1)
+    info = A.RtCompileInfo()
+    good = pkg.upload_options(A.RT_LAYOUT_REFERENCE_COUNTERS)
+    assert lib.rt_scene_compile_info_ex(C.byref(hs.desc), C.byref(good), C.byref(info)) == A.RT_OK and info.n_spheres > 400
+    for flags, word in ((1 << 20, b"unknown"), (A.RT_LAYOUT_LISTS_AS_REFERENCE | A.RT_LAYOUT_LISTS_CULLED, b"both ways"),
+                        (A.RT_LAYOUT_NO_MEMBER_BOXES | A.RT_LAYOUT_MEMBER_BOXES, b"both ways")):
+        bad = pkg.upload_options(flags)
+        assert lib.rt_scene_compile_info_ex(C.byref(hs.desc), C.byref(bad), C.byref(info)) == A.RT_ERR_INVALID
+        assert word in lib.rt_last_error(None)
+    bad = pkg.upload_options(0); bad.struct_bytes = 0
+    assert lib.rt_scene_compile_info_ex(C.byref(hs.desc), C.byref(bad), C.byref(info)) == A.RT_ERR_INVALID
+    bad = pkg.upload_options(0); bad.list_park_cost = -1.0
+    assert lib.rt_scene_compile_info_ex(C.byref(hs.desc), C.byref(bad), C.byref(info)) == A.RT_ERR_INVALID
+    assert lib.rt_scene_compile_dump_ex(C.byref(hs.desc), C.byref(bad), None, 0, None, None, 0) == A.RT_ERR_INVALID
+
+
+def test_device_worker_threads_without_a_device(pkg):
+    """The host threads a multi-GPU context parks between frames (csrc/rt_multi.cpp DeviceWorkers): every worker runs its job exactly once
+    per frame, for 0, 1 and 7 peers; no device is touched."""
+    lib, A = pkg.lib(), pkg._abi
+    for n in (0, 1, 7):
+        assert lib.rt_test_device_workers(n, 200) == A.RT_OK
+    assert lib.rt_test_device_workers(-1, 1) == A.RT_ERR_INVALID
