@@ -112,6 +112,8 @@ struct RenderDev {
     uint32_t tile_slack;          // the tile of pixel q is within [q / ts^2, q / ts^2 + tile_slack] (edge tiles are clipped)
     FastDiv div_ts2, div_tiles_x, div_sq_row, div_item_tile;   // ts^2, tiles_x, ts / 8, ts^2 * n_blocks
     FastDiv div_nblocks, div_width, div_ts, div_shards;        // n_blocks, width, tile_size, shard_count: a path's item id <-> pixel <-> its slot in blocksum
+    uint32_t row_items;           // unsharded renders: work items of one full-height row of tiles (tile_size * width * n_blocks), 0 = not used. Every
+    FastDiv div_row_items;        // such row holds the same number, clipped edge tile or not, so item -> tile is arithmetic (no search in tile_prefix)
     rtd::Float4* blocksum;  // [total_items]: RGB sum of one work item's samples
 };
 

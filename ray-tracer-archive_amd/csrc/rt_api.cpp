@@ -662,6 +662,11 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         rd.div_item_tile = rtk::make_fastdiv(fits ? (uint32_t)item_tile : 0xFFFFFFFFu);
         const uint64_t clipped = (uint64_t)tl.n_local * ts2 - valid_pixels;
         rd.tile_slack = fits ? (uint32_t)std::min<uint64_t>(tl.n_local, clipped / ts2 + 1) : tl.n_local;
+        // one device, every tile: item -> tile by arithmetic (kernels.h RenderDev::row_items)
+        const uint64_t row_items = (uint64_t)tl.ts * prm->width * rd.n_blocks;
+        const bool by_rows = sc == 1u && fits && row_items <= 0xFFFFFFFFull && !(getenv("RT_TILE_SEARCH") && getenv("RT_TILE_SEARCH")[0] == '1');   // (scripts/ only: the search, for A/B)
+        rd.row_items = by_rows ? (uint32_t)row_items : 0u;
+        rd.div_row_items = rtk::make_fastdiv(by_rows ? (uint32_t)row_items : 1u);
     }
 
     if (stats) { std::memset(stats, 0, sizeof(*stats)); }
