@@ -579,6 +579,8 @@ DEVI Rng path_rng(const RenderDev& rd, uint32_t item, bool with_acc, uint32_t st
 constexpr int kShadeBatch = 16;   // DRAIN: lanes on DONE that trigger a shading pass
 // (more resident waves do not help the HBM walk: the config-5 variant forced to 7 waves per SIMD, 72 VGPRs, runs 198.2 ms against 197.2 at
 // 6 waves, and 210.5 ms at 8 with 44 B of scratch)
+// bytes of the record array of an LDS-resident scene as it is staged (kernels.h SceneDev::rec_unit)
+__host__ DEVI uint32_t lds_record_bytes(const SceneDev& sc) { return sc.n_records * (sc.rec_unit > 32u ? sc.rec_unit : 32u); }
 template <int MODE, uint32_t FEAT, bool COUNT, uint32_t TPB, bool DRAIN>
 __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const uint32_t* __restrict__ count_ptr,
                                                  uint32_t* __restrict__ head, uint32_t* __restrict__ count_out_to_zero,
@@ -626,7 +628,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         // shape of LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, LDS address = wave base + lane * 16, no VGPR round
         // trip); all pieces in flight, then one wait + barrier
         const float4* src0 = LDS ? nodes : reinterpret_cast<const float4*>(sc.top_nodes);
-        const uint32_t n4 = 2u * (LDS ? sc.n_records : sc.n_top), s4 = LDS ? sc.n_spheres : 0u, b4 = LDS ? (sc.ext_blob_bytes >> 4) : 0u, tot = n4 + s4 + b4;
+        const uint32_t n4 = LDS ? lds_record_bytes(sc) >> 4 : 2u * sc.n_top, s4 = LDS ? sc.n_spheres : 0u, b4 = LDS ? (sc.ext_blob_bytes >> 4) : 0u, tot = n4 + s4 + b4;
         const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63u, nw = blockDim.x >> 6;
         for (uint32_t base = wave * 64u; base < tot; base += nw * 64u) {
             const uint32_t i = base + ln;
@@ -649,7 +651,8 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         }
     }
     // the three kinds of self-loop records, by address (device_nodes): DONE, IDLE, then the park twins
-    const uint32_t special = top_bytes + sc.n_nodes * 32u, a_done = special, a_idle = special + 32u, a_twins = special + 64u;
+    const uint32_t rec_unit = LDS ? sc.rec_unit : 32u, rec_b = LDS ? sc.rec_b : 16u;
+    const uint32_t special = top_bytes + sc.n_nodes * rec_unit, a_done = special, a_idle = special + rec_unit, a_twins = special + 2u * rec_unit;
     uint32_t w_next = min(wave_id * chunk, count), w_end = min(w_next + chunk, count);
     bool exhausted = false;
 
@@ -698,7 +701,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     auto load_record = [&](uint32_t off, float4& n0, float4& n1) {
         if constexpr (LDS) {
             // k_extend has no static LDS, so the staged copy starts at LDS address 0: the record's address IS its LDS address
-            const F4V a0 = *reinterpret_cast<lds_f4>(off), a1 = *reinterpret_cast<lds_f4>(off + 16u);
+            const F4V a0 = *reinterpret_cast<lds_f4>(off), a1 = *reinterpret_cast<lds_f4>(off + rec_b);
             n0 = make_float4(a0.x, a0.y, a0.z, a0.w); n1 = make_float4(a1.x, a1.y, a1.z, a1.w);
         } else if constexpr (TOP) {
             // every lane reads LDS (a lane outside the top reads slot 0 and drops it); lanes outside the top load from HBM
@@ -722,7 +725,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         else return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(nodes) + (off - top_bytes));
     };
     // rect `idx` of the primitive pass: a0 a1 b0 b1 | k axis, from the staged table (LDS address, stride 32 or 24) or from HBM
-    const uint32_t blob_lds = (2u * sc.n_records + sc.n_spheres) * 16u;   // LDS address of the staged tables behind records and spheres
+    const uint32_t blob_lds = lds_record_bytes(sc) + sc.n_spheres * 16u;   // LDS address of the staged tables behind records and spheres
     const uint32_t rects_lds = (LDS && sc.ext_blob_bytes != 0u && sc.eb_rect_stride != 0u) ? blob_lds + sc.eb_rects : 0u, rect_stride = sc.eb_rect_stride;
     const bool boxes_in_lds = LDS && sc.ext_blob_bytes != 0u;
     const uint32_t boxes_lds = blob_lds + sc.eb_boxes;
@@ -2025,7 +2028,7 @@ static hipError_t launch_extend_g(uint32_t n_groups, size_t lds_bytes, const Sce
 template <int MODE, uint32_t FEAT, bool COUNT>
 static hipError_t launch_drain_c(const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, uint32_t max_count, const uint32_t* count_ptr, uint32_t* head, uint32_t* cz,
                                  unsigned long long* counters, hipStream_t stream) {
-    const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u + sc.ext_blob_bytes) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
+    const size_t lds_bytes = MODE == M_LDS ? ((size_t)lds_record_bytes(sc) + (size_t)sc.n_spheres * 16u + sc.ext_blob_bytes) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
     constexpr uint32_t T = kExtendThreads;
     static thread_local bool checked = false;
     if (!checked) { const hipError_t e = check_no_static_lds(k_extend<MODE, FEAT, COUNT, T, true>); if (e != hipSuccess) return e; checked = true; }
@@ -2036,7 +2039,7 @@ static hipError_t launch_drain_c(const SceneDev& sc, const PoolDev& pool, const 
 template <int MODE, uint32_t FEAT, bool COUNT>
 static hipError_t launch_extend_c(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& pool, const RenderDev& rd, const uint32_t* count_ptr,
                                   uint32_t* head, uint32_t* cz, unsigned long long* counters, hipStream_t stream) {
-    const size_t lds_bytes = MODE == M_LDS ? ((size_t)sc.n_records * 32u + (size_t)sc.n_spheres * 16u + sc.ext_blob_bytes) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
+    const size_t lds_bytes = MODE == M_LDS ? ((size_t)lds_record_bytes(sc) + (size_t)sc.n_spheres * 16u + sc.ext_blob_bytes) : MODE == M_TOP ? (size_t)sc.n_top * 32u : 0u;
     constexpr bool kNoLds = MODE == M_HBM || MODE == M_C16;
     // workgroup sizes compiled for this mode: 256 threads always; 512 and 1024 where an LDS copy limits the groups per CU (a
     // 100 KB scene allows ONE group per CU: only a 1024-thread group then keeps 16 waves on it)

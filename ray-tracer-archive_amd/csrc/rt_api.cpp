@@ -167,6 +167,7 @@ int rt_ctx_destroy(RtCtx* ctx) {
 struct DevNodes {
     std::vector<unsigned char> main, top;   // main: records + DONE + IDLE + twins; top: the LDS copies (M_TOP)
     uint32_t n = 0, n_top = 0, n_twins = 0;
+    uint32_t unit = 32u, b_off = 16u;       // address step from a record to the next, and from a record's first half to its second (kernels.h SceneDev::rec_unit)
     uint32_t records() const { return n + 2u + n_twins; }
 };
 static void node_boxes(const std::vector<rtd::Node>& nodes, std::vector<rtd::NodeDev>& out) {
@@ -192,10 +193,16 @@ static void node_boxes(const std::vector<rtd::Node>& nodes, std::vector<rtd::Nod
         out[i] = rtd::NodeDev{c[0], c[1], h[0], h[1], c[2], h[2], 0u, 0u};
     }
 }
-static bool device_nodes(const std::vector<rtd::Node>& nodes, uint32_t max_top, DevNodes& out) {
+// `layout` (LDS-resident scenes only, max_top = 0; scripts/ only, RT_LDS_RECORDS): 0 = 32-byte records one after the other; 1 = the first
+// halves of all records, then the second halves (a record's address counts in 16-byte steps); 2 = 32-byte records 48 bytes apart. In 0 every
+// first half sits on an even 16-byte column of the LDS's 64 banks and every second half on an odd one: the sixteen lanes of a ds_read_b128
+// group meet in 8 columns, not 16. Measured: the bank-conflict cycles drop, the kernel does not move.
+static bool device_nodes(const std::vector<rtd::Node>& nodes, uint32_t max_top, DevNodes& out, int layout = 0) {
     const size_t n = nodes.size();
     out = DevNodes();
     out.n = (uint32_t)n;
+    if (max_top != 0u) layout = 0;
+    const uint32_t unit = layout == 1 ? 16u : layout == 2 ? 48u : 32u;
     // ---- the top (optional) ----
     std::vector<uint32_t> slot(n, 0xFFFFFFFFu);
     if (max_top != 0u && n != 0) {
@@ -212,15 +219,15 @@ static bool device_nodes(const std::vector<rtd::Node>& nodes, uint32_t max_top, 
         if (cut != 0 && total < n) { uint32_t k = 0; for (size_t i = 0; i < n; ++i) if (depth[i] < cut) slot[i] = k++; out.n_top = k; }
     }
     for (const rtd::Node& nd : nodes) if (nd.leaf != 0u) out.n_twins++;
-    const uint64_t top_bytes = (uint64_t)out.n_top * 32u, total_bytes = top_bytes + (uint64_t)out.records() * 32u;
+    const uint64_t top_bytes = (uint64_t)out.n_top * 32u, total_bytes = top_bytes + (uint64_t)out.records() * std::max(unit, 32u);
     if (total_bytes >= 0xFFFFFFF0ull) return false;                      // 32-bit byte addresses
-    const uint32_t special = (uint32_t)top_bytes + (uint32_t)n * 32u, done = special, idle = special + 32u, twin0 = special + 64u;
-    auto U = [&](size_t i) -> uint32_t { return i >= n ? done : (slot[i] != 0xFFFFFFFFu ? slot[i] * 32u : (uint32_t)top_bytes + (uint32_t)i * 32u); };
+    const uint32_t special = (uint32_t)top_bytes + (uint32_t)n * unit, done = special, idle = special + unit, twin0 = special + 2u * unit;
+    auto U = [&](size_t i) -> uint32_t { return i >= n ? done : (slot[i] != 0xFFFFFFFFu ? slot[i] * 32u : (uint32_t)top_bytes + (uint32_t)i * unit); };
     std::vector<rtd::NodeDev> box;
     node_boxes(nodes, box);
-    out.main.assign((size_t)out.records() * 32, 0);
+    std::vector<rtd::NodeDev> recs((size_t)out.records());               // record k of the array, whatever its address
     out.top.assign((size_t)top_bytes, 0);
-    auto put = [&](uint32_t offset_in_main, const rtd::NodeDev& d) { std::memcpy(out.main.data() + offset_in_main, &d, 32); };
+    auto put = [&](uint32_t address_in_main, const rtd::NodeDev& d) { recs[address_in_main / unit] = d; };
     auto self_loop = [&](uint32_t addr, uint32_t resume, uint32_t payload) {
         rtd::NodeDev d{0.f, 0.f, -1.f, -1.f, 0.f, -1.f, addr, addr};     // h < 0: lo > hi on every axis, the box is never passed
         std::memcpy(&d.cx, &resume, 4); std::memcpy(&d.cy, &payload, 4);
@@ -231,15 +238,24 @@ static bool device_nodes(const std::vector<rtd::Node>& nodes, uint32_t max_top, 
         rtd::NodeDev d = box[i];
         d.skip_bytes = U(nodes[i].skip);
         if (nodes[i].leaf != 0u) {
-            const uint32_t twin = twin0 + 32u * k++;
+            const uint32_t twin = twin0 + unit * k++;
             d.leaf = twin;                                                // hit link -> its park twin
             put(twin - (uint32_t)top_bytes, self_loop(twin, U(nodes[i].skip), nodes[i].leaf));   // resume = first record after the leaf
         } else d.leaf = U(i + 1);                                         // hit link -> the next record in pre-order
-        put((uint32_t)i * 32u, d);
+        put((uint32_t)i * unit, d);
         if (slot[i] != 0xFFFFFFFFu) std::memcpy(out.top.data() + (size_t)slot[i] * 32, &d, 32);
     }
-    put((uint32_t)n * 32u, self_loop(done, done, rtd::LEAF_DONE));
-    put((uint32_t)n * 32u + 32u, self_loop(idle, idle, rtd::LEAF_IDLE));
+    put((uint32_t)n * unit, self_loop(done, done, rtd::LEAF_DONE));
+    put((uint32_t)n * unit + unit, self_loop(idle, idle, rtd::LEAF_IDLE));
+    // the bytes as they lie in memory (and, staged by a linear copy, in LDS)
+    const size_t nr = recs.size();
+    out.unit = unit; out.b_off = layout == 1 ? (uint32_t)nr * 16u : 16u;
+    out.main.assign(nr * std::max(unit, 32u), 0);
+    for (size_t r = 0; r < nr; ++r) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(&recs[r]);
+        std::memcpy(out.main.data() + r * unit, src, 16);
+        std::memcpy(out.main.data() + r * unit + out.b_off, src + 16, 16);
+    }
     return true;
 }
 // Compressed layout (device_types.h Node16) for scenes that do not fit LDS. The grid spans the union of the finite boxes; a corner
@@ -461,7 +477,10 @@ int rti::scene_image_build(const RtSceneDesc* desc, const RtUploadOptions* optio
             if (octants) { im->n16.swap(all); im->oct_stride = stride; im->oct_mask = mask; }
         }
     }
-    if (!im->c16 && !device_nodes(cs.nodes, im->in_lds ? 0u : opt.max_top, im->dn)) { err = "scene: node array beyond 4 GB"; return RT_ERR_UNSUPPORTED; }
+    int lds_layout = 0;
+    if (const char* e = getenv("RT_LDS_RECORDS")) lds_layout = e[0] == '1' ? 1 : e[0] == '2' ? 2 : 0;     // scripts/ only: 1 = halves apart, 2 = 48 bytes apart
+    if (lds_layout == 2 && lds_scene_bytes(cs) + (lds_scene_bytes(cs) - cs.spheres.size() * 16) / 2 > 78 * 1024) lds_layout = 1;   // (two workgroups per CU or not at all)
+    if (!im->c16 && !device_nodes(cs.nodes, im->in_lds ? 0u : opt.max_top, im->dn, im->in_lds ? lds_layout : 0)) { err = "scene: node array beyond 4 GB"; return RT_ERR_UNSUPPORTED; }
     im->top = !im->c16 && im->dn.n_top != 0u;
     // k_shade's small tables as one blob for LDS staging (kernels.h SceneDev::shade_blob): only when it is small
     {
@@ -542,6 +561,7 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     const uint32_t* sb = im.sb; const uint32_t* eb = im.eb;
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
     d.top_nodes = im.top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = im.top ? im.dn.n_top : 0u; d.n_records = im.c16 ? (uint32_t)im.n16.size() : im.dn.records();
+    d.rec_unit = im.c16 ? 16u : im.dn.unit; d.rec_b = im.c16 ? 0u : im.dn.b_off;
     d.oct_stride = im.oct_stride; d.oct_mask = im.oct_mask;
     d.sort_rays = (im.c16 && im.sort_rays) ? 1u : 0u;
     d.wide = im.use_wide ? (const uint4*)s->wide.p : nullptr; d.n_wide = im.use_wide ? im.wide.n_nodes : 0u;
