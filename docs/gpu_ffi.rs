@@ -140,6 +140,7 @@ pub struct RtWideInfo {
 pub struct RtCompileInfo {
     pub n_nodes: u64, pub n_box_nodes: u64, pub n_spheres: u64, pub n_moving: u64, pub n_rects: u64, pub n_tris: u64,
     pub n_media: u64, pub n_xforms: u64, pub n_lights: u64, pub n_materials: u64, pub features: u32, pub fits_lds: u32,
+    pub n_first: u32, pub first: [u32; 4], pub _pad: u32,
 }
 
 pub const RT_OUT_RGB_SUM_F32: u32 = 0;

@@ -248,7 +248,9 @@ int rt_scene_destroy(RtCtx* ctx, RtScene* scene);
  * parity tests compare those counts with the CPU oracle's. Environment variables of the same names as in scripts/ still exist
  * as overrides for experiments; no test and no host depends on them. */
 enum {
-    RT_LAYOUT_LISTS_AS_REFERENCE = 1u,   /* every HittableList member in front of every ray, nothing tested at the start of a walk */
+    RT_LAYOUT_LISTS_AS_REFERENCE = 1u,   /* every HittableList member in front of every ray, nothing tested at the start of a walk (default: members every ray
+                                            meets anyway — a moving sphere, an all-enclosing medium, a sphere of the root BVH as large as the scene — are tested
+                                            when a walk begins and left out of the tree) */
     RT_LAYOUT_LISTS_CULLED = 2u,         /* members behind culling boxes even in a scene that is only a list (default: when the scene holds a BVH of >= 32 members) */
     RT_LAYOUT_NO_MEMBER_BOXES = 4u,      /* the two members of a span-2 BVH node tested directly, as bvh.rs:99-107 does (default: a sphere gets a box of its own in LDS-sized scenes) */
     RT_LAYOUT_MEMBER_BOXES = 8u,         /* ... boxes of their own in any scene */
@@ -358,6 +360,9 @@ typedef struct RtCompileInfo {
     uint64_t n_spheres, n_moving, n_rects, n_tris, n_media, n_xforms, n_lights, n_materials;
     uint32_t features;      /* kernel feature bits the scene needs */
     uint32_t fits_lds;      /* nodes + sphere records fit the LDS staging budget */
+    uint32_t n_first;       /* primitives tested when a walk begins instead of being met by it (none with RT_LAYOUT_LISTS_AS_REFERENCE) ... */
+    uint32_t first[4];      /* ... as leaf words: kind << 28 | count << 24 | first index (kind 1 = sphere, 2 = moving sphere, 5 = medium); they are not in the node records */
+    uint32_t _pad;
 } RtCompileInfo;
 int rt_scene_compile_info(const RtSceneDesc* desc, RtCompileInfo* out);
 int rt_scene_compile_info_ex(const RtSceneDesc* desc, const RtUploadOptions* options, RtCompileInfo* out);

@@ -94,7 +94,7 @@ class RtStats(C.Structure):
 class RtCompileInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_box_nodes", C.c_uint64), ("n_spheres", C.c_uint64), ("n_moving", C.c_uint64), ("n_rects", C.c_uint64),
                 ("n_tris", C.c_uint64), ("n_media", C.c_uint64), ("n_xforms", C.c_uint64), ("n_lights", C.c_uint64), ("n_materials", C.c_uint64),
-                ("features", C.c_uint32), ("fits_lds", C.c_uint32)]
+                ("features", C.c_uint32), ("fits_lds", C.c_uint32), ("n_first", C.c_uint32), ("first", C.c_uint32 * 4), ("_pad", C.c_uint32)]
 
 
 class RtUploadOptions(C.Structure):

@@ -118,7 +118,9 @@ def compile_info(desc, layout_flags=0):
     info = A.RtCompileInfo()
     opt = upload_options(layout_flags)
     _check(lib().rt_scene_compile_info_ex(C.byref(desc), C.byref(opt), C.byref(info)))
-    return {n: getattr(info, n) for n, _ in info._fields_}
+    out = {n: getattr(info, n) for n, _ in info._fields_ if n not in ("first", "_pad")}
+    out["first"] = [int(info.first[k]) for k in range(info.n_first)]
+    return out
 
 
 def wide_layout_check(desc):

@@ -21,6 +21,8 @@ struct SceneDev {
     const rtd::Float4* nodes; uint32_t n_nodes;
     const rtd::Float4* top_nodes; uint32_t n_top;   // top of the tree staged in LDS when the scene does not fit (0: none)
     uint32_t n_records;      // records of `nodes` in all: n_nodes + DONE + IDLE + one park twin per leaf (device_types.h)
+    uint32_t walk_start;     // address of the record a walk begins at: the root (0), or the park twin of the leaf every walk tests first (spheres as large as
+    uint32_t first_leaf;     // the scene, scene_compile.cpp emit_bvh) — its leaf word, which M_C16 walks start with instead (they park by leaf word)
     uint32_t rec_unit, rec_b; // 32-byte records: address step from one record to the next, and from a record's first 16 bytes to its second: 32 and 16
                               // (an LDS-resident scene can be laid out otherwise for experiments: rt_api.cpp device_nodes)
     uint32_t nodes16;        // 1: `nodes` holds 16-byte compressed records (device_types.h Node16), corners on the grid below

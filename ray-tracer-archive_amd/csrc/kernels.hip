@@ -671,7 +671,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
     auto is_parked = [&]() { return C16 ? (pend >> 28) != 0u : node >= a_twins; };
     auto go_idle = [&]() { if (C16) pend = rtd::LEAF_IDLE; else node = a_idle; };
     // M_C16: the walk starts in the record array ordered near-first for its ray's direction octant
-    auto go_root = [&]() { node = 0u; if (C16) { pend = 0u; node = sc.oct_stride * (((d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u)) & sc.oct_mask); } };
+    auto go_root = [&]() { node = sc.walk_start; if (C16) { pend = sc.first_leaf; node = sc.oct_stride * (((d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u)) & sc.oct_mask); } };
     // per-ray constants of the M_C16 slab test: t = q * qa + qb for a corner coordinate q on the scene's grid
     V3 qa = v3(0, 0, 0), qb = v3(0, 0, 0);
     auto set_grid_ray = [&]() {

@@ -167,6 +167,7 @@ int rt_ctx_destroy(RtCtx* ctx) {
 struct DevNodes {
     std::vector<unsigned char> main, top;   // main: records + DONE + IDLE + twins; top: the LDS copies (M_TOP)
     uint32_t n = 0, n_top = 0, n_twins = 0;
+    uint32_t walk_start = 0;                // address of the record a walk begins at: the root, or the park twin of the leaf tested first
     uint32_t unit = 32u, b_off = 16u;       // address step from a record to the next, and from a record's first half to its second (kernels.h SceneDev::rec_unit)
     uint32_t records() const { return n + 2u + n_twins; }
 };
@@ -197,7 +198,8 @@ static void node_boxes(const std::vector<rtd::Node>& nodes, std::vector<rtd::Nod
 // halves of all records, then the second halves (a record's address counts in 16-byte steps); 2 = 32-byte records 48 bytes apart. In 0 every
 // first half sits on an even 16-byte column of the LDS's 64 banks and every second half on an odd one: the sixteen lanes of a ds_read_b128
 // group meet in 8 columns, not 16. Measured: the bank-conflict cycles drop, the kernel does not move.
-static bool device_nodes(const std::vector<rtd::Node>& nodes, uint32_t max_top, DevNodes& out, int layout = 0) {
+// `first_leaf`: leaf word of primitives every walk tests before it enters the tree (0: none) — a park twin of its own that resumes at the root.
+static bool device_nodes(const std::vector<rtd::Node>& nodes, uint32_t max_top, DevNodes& out, int layout = 0, uint32_t first_leaf = 0u) {
     const size_t n = nodes.size();
     out = DevNodes();
     out.n = (uint32_t)n;
@@ -219,6 +221,7 @@ static bool device_nodes(const std::vector<rtd::Node>& nodes, uint32_t max_top, 
         if (cut != 0 && total < n) { uint32_t k = 0; for (size_t i = 0; i < n; ++i) if (depth[i] < cut) slot[i] = k++; out.n_top = k; }
     }
     for (const rtd::Node& nd : nodes) if (nd.leaf != 0u) out.n_twins++;
+    if (first_leaf != 0u) out.n_twins++;
     const uint64_t top_bytes = (uint64_t)out.n_top * 32u, total_bytes = top_bytes + (uint64_t)out.records() * std::max(unit, 32u);
     if (total_bytes >= 0xFFFFFFF0ull) return false;                      // 32-bit byte addresses
     const uint32_t special = (uint32_t)top_bytes + (uint32_t)n * unit, done = special, idle = special + unit, twin0 = special + 2u * unit;
@@ -245,6 +248,11 @@ static bool device_nodes(const std::vector<rtd::Node>& nodes, uint32_t max_top, 
         put((uint32_t)i * unit, d);
         if (slot[i] != 0xFFFFFFFFu) std::memcpy(out.top.data() + (size_t)slot[i] * 32, &d, 32);
     }
+    if (first_leaf != 0u) {
+        const uint32_t twin = twin0 + unit * k++;
+        put(twin - (uint32_t)top_bytes, self_loop(twin, U(0), first_leaf));
+        out.walk_start = twin;
+    } else out.walk_start = U(0);
     put((uint32_t)n * unit, self_loop(done, done, rtd::LEAF_DONE));
     put((uint32_t)n * unit + unit, self_loop(idle, idle, rtd::LEAF_IDLE));
     // the bytes as they lie in memory (and, staged by a linear copy, in LDS)
@@ -390,7 +398,8 @@ static rti::UploadOpts resolve_options(const RtUploadOptions* o) {
     rti::UploadOpts u;
     if (o && o->struct_bytes >= 8u) {
         const uint32_t f = o->layout_flags;
-        if (f & RT_LAYOUT_LISTS_AS_REFERENCE) u.compile.cull_lists = 0; else if (f & RT_LAYOUT_LISTS_CULLED) u.compile.cull_lists = 1;
+        if (f & RT_LAYOUT_LISTS_AS_REFERENCE) { u.compile.cull_lists = 0; u.compile.big_spheres_first = false; }   // "nothing tested at the start of a walk"
+        else if (f & RT_LAYOUT_LISTS_CULLED) u.compile.cull_lists = 1;
         if (f & RT_LAYOUT_NO_MEMBER_BOXES) u.compile.member_boxes = 0; else if (f & RT_LAYOUT_MEMBER_BOXES) u.compile.member_boxes = 1;
         u.octant_order = !(f & RT_LAYOUT_CHILD_ORDER_AS_REFERENCE);
         u.lds_scene = !(f & RT_LAYOUT_SCENE_IN_HBM);
@@ -398,6 +407,7 @@ static rti::UploadOpts resolve_options(const RtUploadOptions* o) {
         u.shade_lds = u.perlin_lds = !(f & RT_LAYOUT_NO_SHADE_TABLES_IN_LDS);
         u.extend_lds_tables = !(f & RT_LAYOUT_NO_EXTEND_TABLES_IN_LDS);
         u.wide_nodes = (f & RT_LAYOUT_WIDE_NODES) != 0u;
+        if (u.wide_nodes) u.compile.big_spheres_first = false;      // the 8-wide walk tests nothing before the tree
         if (o->struct_bytes >= 12u && o->lds_top_records) u.max_top = o->lds_top_records;
         if (o->struct_bytes >= 16u && o->octant_axes) u.octant_axes = 8u | (o->octant_axes & 7u);
         if (o->struct_bytes >= 20u) u.compile.leaf_collapse = o->leaf_collapse;
@@ -405,6 +415,7 @@ static rti::UploadOpts resolve_options(const RtUploadOptions* o) {
     }
     auto env = [](const char* n) -> const char* { const char* e = getenv(n); return e && e[0] ? e : nullptr; };
     if (const char* e = env("RT_LIST_CULL")) u.compile.cull_lists = e[0] == '2' ? 1 : (e[0] == '0' ? 0 : u.compile.cull_lists);
+    if (const char* e = env("RT_BIG_SPHERES_FIRST")) u.compile.big_spheres_first = e[0] != '0';
     if (const char* e = env("RT_PAIR_BOXES")) u.compile.member_boxes = e[0] == '2' ? 1 : (e[0] == '0' ? 0 : u.compile.member_boxes);
     if (const char* e = env("RT_LIST_PARK_COST")) u.compile.park_cost = std::max(0.0, std::atof(e));
     if (const char* e = env("RT_LEAF_COLLAPSE")) u.compile.leaf_collapse = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -416,7 +427,7 @@ static rti::UploadOpts resolve_options(const RtUploadOptions* o) {
     if (const char* e = env("RT_SHADE_LDS")) u.shade_lds = u.shade_lds && e[0] != '0';
     if (const char* e = env("RT_SHADE_PERLIN_LDS")) u.perlin_lds = e[0] != '0';
     if (const char* e = env("RT_EXTEND_LDS_TABLES")) u.extend_lds_tables = u.extend_lds_tables && e[0] != '0';
-    if (const char* e = env("RT_WIDE_NODES")) u.wide_nodes = e[0] != '0';
+    if (const char* e = env("RT_WIDE_NODES")) { u.wide_nodes = e[0] != '0'; if (u.wide_nodes) u.compile.big_spheres_first = false; }
     u.max_top = std::min<uint32_t>(u.max_top, (128u * 1024u) / 32u);
     return u;
 }
@@ -450,7 +461,7 @@ int rti::scene_image_build(const RtSceneDesc* desc, const RtUploadOptions* optio
     if (const char* e = getenv("RT_SORT_RAYS")) im->sort_rays = e[0] != '0';     // scripts/ only
     // RT_LAYOUT_WIDE_NODES: a static BVH in HBM (spheres / rects / triangles / boxes under box nodes only) walked 8 lanes to a ray over an
     // 8-wide tree (kernels.hip k_extend_wide) instead of the binary records below.
-    if (!im->in_lds && opt.wide_nodes && opt.node16 && (im->features & ~(rtk::F_RECT | rtk::F_TRI)) == 0u && rtw::eligible(cs.nodes)) {
+    if (!im->in_lds && opt.wide_nodes && opt.node16 && (im->features & ~(rtk::F_RECT | rtk::F_TRI)) == 0u && cs.prologue.empty() && cs.first_leaf == 0u && rtw::eligible(cs.nodes)) {   // (k_extend_wide tests nothing before the tree)
         double extent = 0.0;
         for (int a = 0; a < 3; ++a) extent = std::max(extent, std::max(std::fabs((double)cs.nodes[0].mn[a]), std::fabs((double)cs.nodes[0].mx[a])));
         std::string werr;
@@ -480,7 +491,7 @@ int rti::scene_image_build(const RtSceneDesc* desc, const RtUploadOptions* optio
     int lds_layout = 0;
     if (const char* e = getenv("RT_LDS_RECORDS")) lds_layout = e[0] == '1' ? 1 : e[0] == '2' ? 2 : 0;     // scripts/ only: 1 = halves apart, 2 = 48 bytes apart
     if (lds_layout == 2 && lds_scene_bytes(cs) + (lds_scene_bytes(cs) - cs.spheres.size() * 16) / 2 > 78 * 1024) lds_layout = 1;   // (two workgroups per CU or not at all)
-    if (!im->c16 && !device_nodes(cs.nodes, im->in_lds ? 0u : opt.max_top, im->dn, im->in_lds ? lds_layout : 0)) { err = "scene: node array beyond 4 GB"; return RT_ERR_UNSUPPORTED; }
+    if (!im->c16 && !device_nodes(cs.nodes, im->in_lds ? 0u : opt.max_top, im->dn, im->in_lds ? lds_layout : 0, cs.first_leaf)) { err = "scene: node array beyond 4 GB"; return RT_ERR_UNSUPPORTED; }
     im->top = !im->c16 && im->dn.n_top != 0u;
     // k_shade's small tables as one blob for LDS staging (kernels.h SceneDev::shade_blob): only when it is small
     {
@@ -562,6 +573,7 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     d.nodes = (const rtd::Float4*)s->nodes.p; d.n_nodes = (uint32_t)cs.nodes.size();
     d.top_nodes = im.top ? (const rtd::Float4*)s->top_nodes.p : nullptr; d.n_top = im.top ? im.dn.n_top : 0u; d.n_records = im.c16 ? (uint32_t)im.n16.size() : im.dn.records();
     d.rec_unit = im.c16 ? 16u : im.dn.unit; d.rec_b = im.c16 ? 0u : im.dn.b_off;
+    d.walk_start = im.c16 ? 0u : im.dn.walk_start; d.first_leaf = cs.first_leaf;
     d.oct_stride = im.oct_stride; d.oct_mask = im.oct_mask;
     d.sort_rays = (im.c16 && im.sort_rays) ? 1u : 0u;
     d.wide = im.use_wide ? (const uint4*)s->wide.p : nullptr; d.n_wide = im.use_wide ? im.wide.n_nodes : 0u;
@@ -945,6 +957,12 @@ int rt_scene_compile_info_ex(const RtSceneDesc* desc, const RtUploadOptions* opt
     out->n_lights = cs.lights.size(); out->n_materials = cs.mat_b.size();
     out->features = scene_features(cs);
     out->fits_lds = lds_scene_bytes(cs) <= kLdsSceneBudget ? 1u : 0u;
+    {   // what a walk tests before it enters the tree: the root list's every-ray members, then the root BVH's scene-sized spheres
+        std::vector<uint32_t> first = cs.prologue;
+        if (cs.first_leaf != 0u) first.push_back(cs.first_leaf);
+        out->n_first = (uint32_t)std::min<size_t>(first.size(), 4); out->_pad = 0u;
+        for (uint32_t k = 0; k < 4u; ++k) out->first[k] = k < first.size() ? first[k] : 0u;
+    }
     return RT_OK;
 }
 
@@ -1011,7 +1029,8 @@ int rt_scene_wide_layout_check(const RtSceneDesc* desc, RtWideInfo* out) {
     if (!desc || !out) return set_err(nullptr, RT_ERR_INVALID, "null argument");
     std::memset(out, 0, sizeof(*out));
     rtc::CompiledScene cs;
-    const int rc = rtc::compile_scene(*desc, cs);
+    rtc::CompileOptions copt; copt.big_spheres_first = false;      // (the 8-wide walk tests nothing before the tree)
+    const int rc = rtc::compile_scene(*desc, copt, cs);
     if (rc != RT_OK) return set_err(nullptr, rc, "scene: " + cs.error);
     if (!rtw::eligible(cs.nodes)) return set_err(nullptr, RT_ERR_UNSUPPORTED, "not a static BVH: the scene keeps the binary walk");
     double extent = 0.0;

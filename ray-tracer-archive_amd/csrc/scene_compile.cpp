@@ -52,6 +52,7 @@ struct Compiler {
     CompiledScene& out;
     std::map<std::pair<long long, std::pair<long long, std::pair<long long, long long>>>, uint32_t> xform_cache;
     bool box_pair_members = false;
+    bool big_spheres_first = true;
     bool cull_lists = true;   // HittableList members behind culling boxes (emit_list_culled); RT_LIST_CULL=0: every member probed by every ray, as the reference does
     double park_cost = 6.0;   // what a stop of the walk at a leaf costs, in primitive tests (RT_LIST_PARK_COST)
     std::map<std::vector<long long>, uint32_t> wrap_cache;
@@ -228,7 +229,7 @@ struct Compiler {
         case RT_HIT_SPHERE:
             out.spheres.push_back(rtd::Float4{(float)p[0], (float)p[1], (float)p[2], (float)p[3]});
             out.sphere_meta.push_back(meta_for(h, ctx));
-            push_leaf_node(rtd::LT_SPHERE, (uint32_t)out.sphere_meta.size() - 1, 1);
+            if (!to_prologue) push_leaf_node(rtd::LT_SPHERE, (uint32_t)out.sphere_meta.size() - 1, 1);     // (else: emit_bvh's first_leaf names it)
             break;
         case RT_HIT_MOVING_SPHERE:
             out.moving.push_back(rtd::Float4{(float)p[0], (float)p[1], (float)p[2], (float)p[8]});
@@ -433,8 +434,17 @@ struct Compiler {
     // ---- BVH ----
     struct Build { std::vector<int> obj; std::vector<double> key[3]; std::vector<Box3> box; uint64_t axis_state; };
 
+    // The BVH every ray enters first: the world itself, or a member of the world list.
+    bool every_ray_enters(int id, const Chain& ctx) const {
+        if (!ctx.identity || !ctx.ops.empty()) return false;
+        if (id == d.world) return true;
+        const RtHittable& w = d.hittables[d.world];
+        if (w.kind != RT_HIT_LIST) return false;
+        for (int c = 0; c < w.n_children; ++c) if ((uint64_t)(w.first_child + c) < d.n_children && d.children[w.first_child + c] == id) return true;
+        return false;
+    }
     void emit_bvh(int id, const RtHittable& h, const Chain& ctx, int depth) {
-        const int n = h.n_children;
+        int n = h.n_children;
         if (n <= 0) { fail("empty BVH"); return; }
         Build B;
         B.obj.resize(n); B.box.resize(n); for (int a = 0; a < 3; ++a) B.key[a].resize(n);
@@ -445,6 +455,31 @@ struct Compiler {
             if (!bbox(cid, 0.0, 0.0, k0) || !bbox(cid, h.p[0], h.p[1], B.box[c])) { fail("No bounding box in BVHNode constructor."); return; }   // bvh.rs:19-21,123-127
             B.obj[c] = cid;
             for (int a = 0; a < 3; ++a) B.key[a][c] = k0.mn[a];
+        }
+        // A sphere whose box is most of this BVH's box (the r = 1000 ground of the books' scenes) spoils every box above it — they all grow to
+        // the scene's size, and nearly every ray walks down to that sphere — and is met by nearly every ray anyway. Out of the tree with it:
+        // it is tested when a walk begins (a walk starts parked at a leaf of its own, kernels.h SceneDev::walk_start: the sphere is tested in the
+        // wave's next sphere pass like any leaf's), the walk then starts with that hit's t_max, and the tree of the others
+        // keeps tight boxes. BVHNode::hit keeps the closest of its members' hits whatever their order (bvh.rs:134-143), so the hit is the
+        // same; the test COUNTS are not the reference's (CompileOptions::big_spheres_first = false restores those).
+        if (big_spheres_first && out.first_leaf == 0u && n >= 3 && every_ray_enters(id, ctx)) {
+            Box3 all = B.box[0];
+            for (int c = 1; c < n; ++c) all = surrounding(all, B.box[c]);
+            std::vector<char> big((size_t)n, 0); int n_big = 0;
+            for (int c = 0; c < n && n_big < 4; ++c) {
+                const RtHittable* m = H(B.obj[c]); if (!m) return;
+                if (m->kind == RT_HIT_SPHERE && half_area(B.box[c]) >= 0.5 * half_area(all)) { big[(size_t)c] = 1; ++n_big; }
+            }
+            if (n_big != 0 && n - n_big >= 2) {
+                Build K; for (int a = 0; a < 3; ++a) K.key[a].reserve((size_t)(n - n_big));
+                const uint32_t first = (uint32_t)out.sphere_meta.size();
+                for (int c = 0; c < n; ++c) {
+                    if (big[(size_t)c]) { to_prologue = true; emit(B.obj[c], ctx, depth + 1); to_prologue = false; continue; }   // (consecutive in the sphere table)
+                    K.obj.push_back(B.obj[c]); K.box.push_back(B.box[c]); for (int a = 0; a < 3; ++a) K.key[a].push_back(B.key[a][c]);
+                }
+                out.first_leaf = rtd::make_leaf(rtd::LT_SPHERE, first, (uint32_t)n_big);
+                B = std::move(K); n -= n_big;
+            }
         }
         std::vector<int> order(n); for (int i = 0; i < n; ++i) order[i] = i;
         B.axis_state = fin(d.bvh_seed + GAMMA * (uint64_t)(id + 1));
@@ -787,6 +822,7 @@ int compile_scene(const RtSceneDesc& desc, const CompileOptions& opt, CompiledSc
     c.cull_lists = opt.cull_lists < 0 ? bvh_members >= 32 : opt.cull_lists != 0;
     c.box_pair_members = opt.member_boxes < 0 ? desc.n_hittables < 8192 : opt.member_boxes != 0;      // scenes of that size are LDS-resident (rt_api.cpp: 144 KB of records and spheres)
     c.park_cost = std::max(0.0, opt.park_cost);
+    c.big_spheres_first = opt.big_spheres_first;
     out.xforms.push_back(rtd::Xform{0.f, 1.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
     out.wraps.push_back(rtd::Wrap{});
     c.compile_materials();

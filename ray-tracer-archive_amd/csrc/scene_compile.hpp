@@ -23,6 +23,7 @@ struct CompiledScene {
     std::vector<rtd::PerlinTable> perlins;
     std::vector<rtd::Image> images;    std::vector<uint8_t> image_bytes;
     std::vector<rtd::Light> lights;
+    uint32_t first_leaf = 0;                                                 // leaf word of the spheres a walk tests before it enters the tree (emit_bvh: spheres as large as the scene), 0: none
     std::vector<uint32_t> prologue;                                          // leaf payloads of the root list's every-ray members (scene_compile.cpp: prologue_member)
     int background_mode = 0; float background[3] = {0, 0, 0};
     bool has_lights = false;
@@ -37,6 +38,7 @@ struct CompileOptions {
     int member_boxes = -1;      // a sphere of a span-2 BVH node / SAH leaf gets a box of its own: -1 = in LDS-sized scenes, 0 = never (bvh.rs:99-107), 1 = always
     double park_cost = 6.0;     // a stop of the walk at a leaf, in primitive tests (grouping of culled list members)
     uint32_t leaf_collapse = 0; // a box node whose subtree is <= n primitives of one kind becomes a leaf (0/1: off)
+    bool big_spheres_first = true;  // a sphere of the root BVH whose box is most of the scene (a ground sphere) is tested when a walk begins, not met by it
 };
 
 // Returns RT_OK or a negative RtStatus; `out.error` explains.

@@ -3,12 +3,33 @@ import numpy as np
 import pytest
 
 
-def traverse(nodes, spheres, o, d, tmin=0.001):
-    """Python walk of the dumped threaded BVH (spheres only): returns (t, sphere index, node visits)."""
+def sphere_root(spheres, k, o, d, a, tmin, best):
+    c, r = spheres[k, :3].astype(float), float(spheres[k, 3])
+    oc = o - c
+    hb, cc = oc @ d, oc @ oc - r * r
+    det = hb * hb - a * cc
+    if det < 0:
+        return None
+    sq = np.sqrt(det)
+    root = (-hb - sq) / a
+    if root < tmin or best < root:
+        root = (-hb + sq) / a
+        if root < tmin or best < root:
+            return None
+    return root
+
+
+def traverse(nodes, spheres, o, d, tmin=0.001, first=()):
+    """Python walk of the dumped threaded BVH (spheres only): returns (t, sphere index, node visits). `first`: spheres tested before the
+    walk begins (RtCompileInfo.first)."""
     i, n = 0, len(nodes)
     best, hit, visits = np.inf, -1, 0
     o, d = np.asarray(o, float), np.asarray(d, float)
     a = d @ d
+    for k in first:
+        root = sphere_root(spheres, k, o, d, a, tmin, best)
+        if root is not None:
+            best, hit = root, k
     while i < n:
         nd = nodes[i]
         boxed = np.isfinite(nd["mn"][0])
@@ -52,12 +73,22 @@ def traverse(nodes, spheres, o, d, tmin=0.001):
     return best, hit, visits
 
 
-def test_threaded_bvh_equals_oracle_world_hit(pkg, orc):
+@pytest.mark.parametrize("layout", ["default", "reference"])
+def test_threaded_bvh_equals_oracle_world_hit(pkg, orc, layout):
+    """The compiled records, walked in Python, give the oracle's world.hit — in the default layout (the ground sphere is tested when a walk
+    begins and is not in the tree: RtCompileInfo.first) and in the reference's (every member in the tree)."""
     hs = pkg.HostScene("book1", 1)
-    nodes, spheres, meta = pkg.compile_dump(hs.desc)
-    info = pkg.compile_info(hs.desc)
+    flags = pkg._abi.RT_LAYOUT_LISTS_AS_REFERENCE if layout == "reference" else 0
+    nodes, spheres, meta = pkg.compile_dump(hs.desc, flags)
+    info = pkg.compile_info(hs.desc, flags)
     assert info["n_box_nodes"] == len(nodes) == 511 or info["n_box_nodes"] <= len(nodes)
     assert info["fits_lds"] == 1 and info["features"] == 0
+    if layout == "reference":
+        assert info["first"] == []
+    else:
+        assert len(info["first"]) == 1 and info["first"][0] >> 28 == 1          # one sphere: the r = 1000 ground
+        assert spheres[info["first"][0] & 0xFFFFFF, 3] == 1000.0
+    first = [k for w in info["first"] for k in range(w & 0xFFFFFF, (w & 0xFFFFFF) + ((w >> 24) & 15))]
     # every skip edge goes forward; the last subtree's skip is the end sentinel
     assert np.all(nodes["skip"] > np.arange(len(nodes))) and nodes["skip"].max() == len(nodes)
     rng = np.random.default_rng(11)
@@ -65,7 +96,7 @@ def test_threaded_bvh_equals_oracle_world_hit(pkg, orc):
     for _ in range(150):
         o = np.array([13, 2, 3]) + rng.normal(size=3) * 0.5
         d = rng.normal(size=3) * [1, 0.3, 1] - o / 4
-        t, k, _ = traverse(nodes, spheres, o, d)
+        t, k, _ = traverse(nodes, spheres, o, d, first=first)
         ref = orc.world_hit(hs.desc, o, d)
         assert (ref is None) == (k < 0)
         if ref is not None:
@@ -212,27 +243,32 @@ def test_sah_tree_is_a_valid_accelerator(pkg, orc):
     A = pkg._abi
     rng = np.random.default_rng(21)
     visits = {}
-    for builder in (A.RT_BVH_REFERENCE, A.RT_BVH_SAH):
+    for builder, flags in ((A.RT_BVH_REFERENCE, 0), (A.RT_BVH_SAH, 0), (A.RT_BVH_REFERENCE, A.RT_LAYOUT_LISTS_AS_REFERENCE)):
         b = pkg.SceneBuilder(bvh_seed=5, bvh_builder=builder)
         m = b.lambertian((0.5, 0.5, 0.5))
         r2 = np.random.default_rng(8)
         ids = [b.sphere(r2.uniform(-10, 10, 3) * [1, 0.2, 1], r2.uniform(0.1, 0.8), m) for _ in range(300)] + [b.sphere((0, -1000, 0), 998, m)]
         desc = b.desc(b.bvh(ids))
-        nodes, spheres, _ = pkg.compile_dump(desc)
+        nodes, spheres, _ = pkg.compile_dump(desc, flags)
+        first = [k for w in pkg.compile_info(desc, flags)["first"] for k in range(w & 0xFFFFFF, (w & 0xFFFFFF) + ((w >> 24) & 15))]
+        assert len(first) == (0 if flags else 1)                # the ground sphere is tested before the walk, unless the layout is the reference's
         assert np.all(nodes["skip"] > np.arange(len(nodes)))
         total = 0
         rr = np.random.default_rng(9)
         for _ in range(120):
             o = rr.uniform(-12, 12, 3) * [1, 0.3, 1] + [0, 3, 0]
             d = rr.normal(size=3)
-            t, k, v = traverse(nodes, spheres, o, d)
+            t, k, v = traverse(nodes, spheres, o, d, first=first)
             ref = orc.world_hit(desc, o, d)
             assert (ref is None) == (k < 0)
             if ref is not None:
                 assert t == pytest.approx(ref["t"], rel=1e-5)
             total += v
-        visits[builder] = total
-    assert visits[A.RT_BVH_SAH] < 0.8 * visits[A.RT_BVH_REFERENCE]
+        visits[(builder, flags)] = total
+    print("box visits:", visits)
+    assert visits[(A.RT_BVH_SAH, 0)] < 0.8 * visits[(A.RT_BVH_REFERENCE, 0)]
+    # the ground sphere out of the reference-shaped tree: the boxes above it shrink and the walk starts with its t_max
+    assert visits[(A.RT_BVH_REFERENCE, 0)] < 0.8 * visits[(A.RT_BVH_REFERENCE, A.RT_LAYOUT_LISTS_AS_REFERENCE)]
 
 
 def test_top_of_tree_layout(pkg):
