@@ -462,7 +462,9 @@ struct Compiler {
         // wave's next sphere pass like any leaf's), the walk then starts with that hit's t_max, and the tree of the others
         // keeps tight boxes. BVHNode::hit keeps the closest of its members' hits whatever their order (bvh.rs:134-143), so the hit is the
         // same; the test COUNTS are not the reference's (CompileOptions::big_spheres_first = false restores those).
-        if (big_spheres_first && out.first_leaf == 0u && n >= 3 && every_ray_enters(id, ctx)) {
+        // (Not with RT_BVH_SAH: that builder splits such a sphere off near the root by itself — book-1 on the SAH tree 35.6 ms with it in the tree,
+        // 36.7 with it tested first.)
+        if (big_spheres_first && d.bvh_builder != RT_BVH_SAH && out.first_leaf == 0u && n >= 3 && every_ray_enters(id, ctx)) {
             Box3 all = B.box[0];
             for (int c = 1; c < n; ++c) all = surrounding(all, B.box[c]);
             std::vector<char> big((size_t)n, 0); int n_big = 0;
