@@ -174,7 +174,11 @@ def test_sah_builder_gives_the_same_picture(pkg, gpu):
     a, sa = gpu.render(gpu.upload(ref_s.desc), cam, prm)
     b, sb = gpu.render(gpu.upload(sah_s.desc), cam, prm)
     assert np.array_equal(a, b)
-    assert sb["node_tests"] < 0.7 * sa["node_tests"] and sa["segments"] == sb["segments"]
+    # ... and the reference's own tree (the ground sphere IN it; by default it is tested when a walk begins and left out): the same picture again
+    c, sc = gpu.render(gpu.upload(ref_s.desc, A.RT_LAYOUT_LISTS_AS_REFERENCE), cam, prm)
+    assert np.array_equal(a, c)
+    assert sa["segments"] == sb["segments"] == sc["segments"]
+    assert sb["node_tests"] < 0.8 * sa["node_tests"] < 0.8 * 0.85 * sc["node_tests"]
 
 
 def test_config5_million_spheres_and_mesh(pkg, orc, gpu):
