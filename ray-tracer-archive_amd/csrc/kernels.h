@@ -116,6 +116,10 @@ struct RenderDev {
     uint32_t tile_slack;          // the tile of pixel q is within [q / ts^2, q / ts^2 + tile_slack] (edge tiles are clipped)
     FastDiv div_ts2, div_tiles_x, div_sq_row, div_item_tile;   // ts^2, tiles_x, ts / 8, ts^2 * n_blocks
     FastDiv div_nblocks, div_width, div_ts, div_shards;        // n_blocks, width, tile_size, shard_count: a path's item id <-> pixel <-> its slot in blocksum
+    // The sphere every walk tests first (SceneDev::walk_start), tested where the ray is MADE — k_generate, k_shade: full waves — instead of
+    // in the walk's first primitive pass (a third of a wave's lanes): the ray record's time slot then carries that hit's t (or inf) to k_extend.
+    // Only in scenes without motion (the time is used by nothing), with ONE such sphere, and not while counting.
+    uint32_t first_in_shade, first_id; float first_sphere[4];
     uint32_t row_items;           // unsharded renders: work items of one full-height row of tiles (tile_size * width * n_blocks), 0 = not used. Every
     FastDiv div_row_items;        // such row holds the same number, clipped edge tile or not, so item -> tile is arithmetic (no search in tile_prefix)
     rtd::Float4* blocksum;  // [total_items]: RGB sum of one work item's samples
@@ -143,6 +147,8 @@ hipError_t launch_drain(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev&
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneDev& sc, const PoolDev& in, const PoolDev& out, const RenderDev& rd, uint32_t max_count,
                         const uint32_t* count_in, uint32_t* count_out, uint32_t* head_to_zero, unsigned long long* counters,
                         bool count, hipStream_t stream);
+// whether the kernels compiled for these features can test the first sphere where a ray is made (RenderDev::first_in_shade)
+bool can_test_first_in_shade(uint32_t features);
 hipError_t launch_resolve(const RenderDev& rd, float* out, uint32_t n_valid_pixels, hipStream_t stream);
 hipError_t launch_write_color(const float* rgb_sum, uint32_t n_pixels, uint32_t spp, uint8_t* rgb8, hipStream_t stream);
 // multi-GPU root: gathered shard buffers -> full frame (rt_multi.cpp)

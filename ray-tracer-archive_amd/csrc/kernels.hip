@@ -471,6 +471,11 @@ DEVI uint32_t item_slot(const RenderDev& rd, uint32_t item) {
     return before + blk * (w * h) + p;
 }
 
+// RenderDev::first_in_shade: the hit of the ray (o, d), which starts on primitive `from`, with the sphere every walk tests first — the
+// very calls the walk's sphere pass would make for it (kernels.hip LT_SPHERE pass), so the frame does not depend on where it is tested.
+// Returns t, or +inf.
+DEVI float first_sphere_hit(const RenderDev& rd, V3 o, V3 d, uint32_t from);
+
 // ------------------------------------------------------------------------------------------------
 // k_extend — world.hit for the whole pool
 // ------------------------------------------------------------------------------------------------
@@ -789,6 +794,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
             const Float4 ro = pool.ray_o[qbase + i], rdv = pool.ray_d[qbase + i], s0 = pool.s0[qbase + i];
             const uint32_t sd = pool.sd[qbase + i];
             o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
+            if (rd.first_in_shade != 0u) tm = 0.f;     // (the slot held the first sphere's t for a k_extend of the other kind; this walk starts parked at that sphere)
             ps.T = v3(s0.x, s0.y, s0.z); ps.work = __float_as_uint(s0.w); ps.from = __float_as_uint(rdv.w);
             uint32_t stored = 0u;
             if (with_acc) { const Float4 s1 = pool.s1[qbase + i]; ps.acc = v3(s1.x, s1.y, s1.z); stored = __float_as_uint(s1.w); }
@@ -829,8 +835,14 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                         const uint32_t smp = rd.block_shift != 0u ? __float_as_uint(pool.s1[qbase + slot].w) : (item - pixel * rd.n_blocks);
                         mkey = path_base(rd.seed, (uint64_t)pixel, smp);
                     }
+                    if (rd.first_in_shade != 0u) {
+                        // the sphere every walk tests first was tested where this ray was made: its t came in the record's time slot
+                        tmax = ot; tm = 0.f; hit_prim = ot < kInf ? rd.first_id : rtd::HIT_NONE;
+                        node = 0u; if (C16) { go_root(); pend = 0u; }
+                    } else {
                     tmax = kInf; hit_prim = rtd::HIT_NONE; go_root();   // address 0 = the root (the first record, or its copy in the top)
                     prologue();
+                    }
                 }
                 w_next += take;
             }
@@ -1452,6 +1464,18 @@ DEVI uint32_t block_alloc_sorted(bool flag, uint32_t key, uint32_t* counter, uin
     return flag ? s_bins[kSortBins + 1u] + s_bins[key] + rank : 0xFFFFFFFFu;
 }
 
+DEVI float first_sphere_hit(const RenderDev& rd, V3 o, V3 d, uint32_t from) {
+    const V3 c = v3(rd.first_sphere[0], rd.first_sphere[1], rd.first_sphere[2]); const float r = rd.first_sphere[3], a = len2(d);
+    float t = kInf, tt;
+    const int fast = rd.first_id == from ? 2 : sphere_fast(o, d, a, c, r, kTMin, kInf, tt);
+    if (fast == 1) t = tt;
+    if (fast == 2) {
+        const bool h = rd.first_id == from ? sphere_hit_from_surface(o, d, a, c, r, kTMin, kInf, tt) : sphere_roots(o, d, a, c, r, kTMin, kInf, tt);
+        if (h) t = tt;
+    }
+    return t;
+}
+
 // A fresh path for work item `work` (first sample of its block).
 DEVI void start_item(const RenderDev& rd, uint32_t work, PathState& s, Rng& g, V3& o, V3& d, float& tm) {
     const WorkItem it = decode_work(rd, work);
@@ -1473,6 +1497,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_generate(PoolDev pool, Render
     if (i < n_init) {
         PathState s; V3 o, d; float tm; Rng g;
         start_item(rd, i, s, g, o, d, tm);
+        if (rd.first_in_shade != 0u) tm = first_sphere_hit(rd, o, d, 0u);         // (the time slot of a motionless scene: kernels.h)
         const uint32_t q = (i >> 9) & (kQueues - 1u), slot = ((i / (512u * kQueues)) << 9) | (i & 511u);
         store_path(pool, q * rd.queue_cap + slot, o, d, tm, s, g.n, 0u, rd.block_shift != 0u);
     }
@@ -1869,6 +1894,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
         const Float4 ro = in.ray_o[qbase + i], rdv = in.ray_d[qbase + i], s0 = in.s0[qbase + i];
         const uint32_t sd = in.sd[qbase + i]; const uint2 hit = in.hit[qbase + i];
         o = v3(ro.x, ro.y, ro.z); d = v3(rdv.x, rdv.y, rdv.z); tm = ro.w;
+        if (rd.first_in_shade != 0u) tm = 0.f;        // the slot carried the first sphere's t to k_extend; nothing moves in such a scene
         s.T = v3(s0.x, s0.y, s0.z); s.work = __float_as_uint(s0.w);
         uint32_t stored = 0u;
         if (with_acc) { const Float4 s1 = in.s1[qbase + i]; s.acc = v3(s1.x, s1.y, s1.z); stored = __float_as_uint(s1.w); }   // else acc = 0: the item is this one sample
@@ -1923,6 +1949,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
             dst = first_lane_u32(base) + lane_rank(m);
         } else dst = block_alloc(alive, count_out, s_scan);
         SSTAMP(4);
+        if (rd.first_in_shade != 0u && alive) tm = first_sphere_hit(rd, o, d, s.from);
         if (alive) store_path(out, qbase + dst, o, d, tm, s, g.n, depth, with_acc);
     }
 #ifdef RT_SHADE_STAMPS
@@ -2183,6 +2210,8 @@ hipError_t launch_generate(const PoolDev& pool, const RenderDev& rd, uint32_t n_
     hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(kShadeThreads), 0, stream, pool, rd, n_init, out_count);
     return hipGetLastError();
 }
+
+bool can_test_first_in_shade(uint32_t features) { return (features & (F_MOVING | F_MEDIUM)) == 0u; }
 
 hipError_t launch_resolve(const RenderDev& rd, float* out, uint32_t n_valid_pixels, hipStream_t stream) {
     const uint32_t blocks = (n_valid_pixels + 255u) / 256u;

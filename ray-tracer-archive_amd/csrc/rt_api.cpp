@@ -600,6 +600,11 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     s->features = im.features;
     s->in_lds = im.in_lds; s->lds_bytes = lds_scene_bytes(cs);
     s->bg_mode = cs.background_mode; for (int i = 0; i < 3; ++i) s->bg[i] = cs.background[i];
+    if (cs.first_leaf != 0u && ((cs.first_leaf >> 24) & 15u) == 1u && (cs.first_leaf >> 28) == rtd::LT_SPHERE) {
+        const uint32_t k = cs.first_leaf & rtd::LEAF_MAX_FIRST;
+        s->first_id = (rtd::LT_SPHERE << 28) | k;
+        s->first_sphere[0] = cs.spheres[k].x; s->first_sphere[1] = cs.spheres[k].y; s->first_sphere[2] = cs.spheres[k].z; s->first_sphere[3] = cs.spheres[k].w;
+    }
     s->n_nodes = cs.nodes.size();
     s->n_prims = cs.sphere_meta.size() + cs.moving_meta.size() + cs.rect_meta.size() + cs.tri_meta.size() + cs.media.size();
     s->bytes = cs.nodes.size() * 32 + cs.spheres.size() * 16 + cs.moving.size() * 16 + cs.rects.size() * 16 + cs.tris.size() * 16 +
@@ -775,6 +780,9 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     const uint32_t n_init = (uint32_t)std::min<uint64_t>(P, total_items);
     rd.n_init = n_init; rd.lineage = P;
     rd.q_lo = 0u; rd.q_n = rtk::kQueues; rd.q_shift = rtk::kQShift;
+    // the ground sphere tested where a ray is made (kernels.h RenderDev::first_in_shade): a scene without motion, one such sphere, no counting
+    rd.first_in_shade = scene->first_id != 0u && rtk::can_test_first_in_shade(scene->features) && !counting && !(getenv("RT_FIRST_IN_SHADE") && getenv("RT_FIRST_IN_SHADE")[0] == '0') ? 1u : 0u;
+    rd.first_id = scene->first_id; for (int k = 0; k < 4; ++k) rd.first_sphere[k] = scene->first_sphere[k];
     HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, n_init, c_count[0], ctx->stream));
     if (timing) { HIP_TRY(ctx, next_event(e1)); spans.push_back({e0, e1, 2}); }
     // The host never waits for an iteration it has just enqueued: the kernels read the pool size from device memory and size-check

@@ -53,6 +53,7 @@ struct RtScene {
         image_bytes, lights, top_nodes, shade_blob, ext_blob, wide;
     rtk::SceneDev dev{};
     uint32_t features = 0; bool in_lds = false;
+    uint32_t first_id = 0; float first_sphere[4] = {0, 0, 0, 0};   // the ONE sphere every walk tests first (hit id, centre + radius), first_id = 0: none or several
     int bg_mode = 0; float bg[3] = {0, 0, 0};
     uint64_t n_nodes = 0, n_prims = 0, bytes = 0, lds_bytes = 0;
 };
