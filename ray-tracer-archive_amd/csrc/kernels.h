@@ -34,6 +34,8 @@ struct SceneDev {
     uint32_t n_prologue, prologue[rtd::MAX_PROLOGUE];   // moving spheres / media every ray meets: tested when a walk begins
     uint32_t n_prim_kinds;   // how many of {sphere, moving sphere, rect, triangle, medium} the scene holds
     const rtd::Float4* spheres; const uint32_t* sphere_meta; uint32_t n_spheres;
+    const rtd::Float4* sphere_mat_a; const uint32_t* sphere_mat_b;   // small scenes: every sphere's material record beside it (mat_a/mat_b by sphere index), so
+                                                                     // that k_shade asks for it together with the sphere instead of after its meta word; else nullptr
     const rtd::Float4* moving; const uint32_t* moving_meta;
     const rtd::Float4* rects; const uint32_t* rect_meta;
     const rtd::Float4* tris; const uint32_t* tri_meta;

@@ -1642,6 +1642,10 @@ DEVI uint32_t shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& 
         const uint32_t type = hit.y >> 28, idx = hit.y & rtd::LEAF_MAX_FIRST;
         uint32_t meta;
         V3 p, n; float hu = 0.f, hv = 0.f; bool ff;
+        // a sphere's material record by sphere index where the scene has that table: asked for now, with the sphere, not after its meta word
+        const bool by_sphere = type == rtd::LT_SPHERE && sc.sphere_mat_a != nullptr;
+        Float4 ma_s = Float4{0.f, 0.f, 0.f, 0.f}; uint32_t mb_s = 0u;
+        if (by_sphere) { ma_s = sc.sphere_mat_a[idx]; mb_s = sc.sphere_mat_b[idx]; }
         if ((FEAT & F_MEDIUM) && type == rtd::LT_MEDIUM) {
             meta = sc.media[idx].meta;
             p = o + d * t; n = v3(1.f, 0.f, 0.f); ff = true;                // constant_medium.rs:62-66
@@ -1718,7 +1722,8 @@ DEVI uint32_t shade_segment(const SceneDev& sc, const RenderDev& rd, V3& o, V3& 
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); s.st_prim = __builtin_amdgcn_s_memtime();
 #endif
         const uint32_t mat = meta & rtd::META_MAT_MASK;
-        const Float4 ma = sc.mat_a[mat]; const uint32_t mb = sc.mat_b[mat];
+        Float4 ma = ma_s; uint32_t mb = mb_s;
+        if (!by_sphere) { ma = sc.mat_a[mat]; mb = sc.mat_b[mat]; }
 #ifdef RT_SHADE_STAMPS
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); s.st_mat = __builtin_amdgcn_s_memtime();
 #endif

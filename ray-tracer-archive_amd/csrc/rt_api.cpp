@@ -563,6 +563,14 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     up(s->rects, cs.rects); up(s->rect_meta, cs.rect_meta); up(s->tris, cs.tris); up(s->tri_meta, cs.tri_meta); up(s->boxes, cs.boxes); up(s->media, cs.media);
     up(s->xforms, cs.xforms); up(s->wraps, cs.wraps); up(s->mat_a, cs.mat_a); up(s->mat_b, cs.mat_b); up(s->textures, cs.textures); up(s->perlins, cs.perlins);
     up(s->images, cs.images); up(s->image_bytes, cs.image_bytes); up(s->lights, cs.lights);
+    // a small scene whose shading tables are not staged in LDS: the material record of every sphere by SPHERE index (one dependent load fewer in
+    // k_shade: book-1 waits ~700 cycles of a wave's ~20 000 for the material's record after the sphere's)
+    std::vector<rtd::Float4> sphere_ma; std::vector<uint32_t> sphere_mb;
+    if (im.blob.empty() && !cs.spheres.empty() && cs.spheres.size() <= 65536 && !(getenv("RT_SPHERE_MATS") && getenv("RT_SPHERE_MATS")[0] == '0')) {
+        sphere_ma.resize(cs.spheres.size()); sphere_mb.resize(cs.spheres.size());
+        for (size_t k = 0; k < cs.spheres.size(); ++k) { const uint32_t m = cs.sphere_meta[k] & rtd::META_MAT_MASK; sphere_ma[k] = cs.mat_a[m]; sphere_mb[k] = cs.mat_b[m]; }
+        up(s->sphere_mat_a, sphere_ma); up(s->sphere_mat_b, sphere_mb);
+    }
     if (im.use_wide) up(s->wide, im.wide.words);
     if (!im.blob.empty()) up(s->shade_blob, im.blob);
     if (!im.eblob.empty()) up(s->ext_blob, im.eblob);
@@ -583,6 +591,7 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     d.n_prim_kinds = (cs.sphere_meta.empty() ? 0u : 1u) + (cs.moving_meta.empty() ? 0u : 1u) + (cs.rect_meta.empty() ? 0u : 1u) +
                      (cs.tri_meta.empty() ? 0u : 1u) + (cs.media.empty() ? 0u : 1u);   // (a Box counts with the rects: their sides)
     d.spheres = (const rtd::Float4*)s->spheres.p; d.sphere_meta = (const uint32_t*)s->sphere_meta.p; d.n_spheres = (uint32_t)cs.spheres.size();
+    if (!sphere_ma.empty()) { d.sphere_mat_a = (const rtd::Float4*)s->sphere_mat_a.p; d.sphere_mat_b = (const uint32_t*)s->sphere_mat_b.p; }
     d.moving = (const rtd::Float4*)s->moving.p; d.moving_meta = (const uint32_t*)s->moving_meta.p;
     d.rects = (const rtd::Float4*)s->rects.p; d.rect_meta = (const uint32_t*)s->rect_meta.p;
     d.tris = (const rtd::Float4*)s->tris.p; d.tri_meta = (const uint32_t*)s->tri_meta.p; d.boxes = (const rtd::Float4*)s->boxes.p;
@@ -630,7 +639,7 @@ int rt_scene_destroy(RtCtx* ctx, RtScene* s) {
     if (!s) return RT_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     DevBuf* all[] = {&s->nodes, &s->spheres, &s->sphere_meta, &s->moving, &s->moving_meta, &s->rects, &s->rect_meta, &s->tris, &s->tri_meta, &s->boxes, &s->media,
-                     &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights, &s->top_nodes, &s->shade_blob, &s->ext_blob, &s->wide};
+                     &s->xforms, &s->wraps, &s->mat_a, &s->mat_b, &s->textures, &s->perlins, &s->images, &s->image_bytes, &s->lights, &s->top_nodes, &s->shade_blob, &s->ext_blob, &s->wide, &s->sphere_mat_a, &s->sphere_mat_b};
     for (DevBuf* b : all) b->release();
     delete s;
     return RT_OK;

@@ -50,7 +50,7 @@ struct RtCtx {
 
 struct RtScene {
     rti::DevBuf nodes, spheres, sphere_meta, moving, moving_meta, rects, rect_meta, tris, tri_meta, boxes, media, xforms, wraps, mat_a, mat_b, textures, perlins, images,
-        image_bytes, lights, top_nodes, shade_blob, ext_blob, wide;
+        image_bytes, lights, top_nodes, shade_blob, ext_blob, wide, sphere_mat_a, sphere_mat_b;
     rtk::SceneDev dev{};
     uint32_t features = 0; bool in_lds = false;
     uint32_t first_id = 0; float first_sphere[4] = {0, 0, 0, 0};   // the ONE sphere every walk tests first (hit id, centre + radius), first_id = 0: none or several
