@@ -527,6 +527,10 @@ constexpr uint32_t kExtendThreads = RT_EXTEND_THREADS;
 constexpr uint32_t kChunk = RT_CHUNK;
 constexpr int kStepsPlain = RT_STEPS, kStepsAll = RT_STEPS_ALL;
 constexpr int kLeafBatch = RT_LEAF_BATCH;
+#ifndef RT_LEAF_BATCH_PLAIN
+#define RT_LEAF_BATCH_PLAIN 16   // ... in the spheres-only variant (book-1, with the ground sphere tested where rays are made: 16: 42.4 ms, 20: 42.8, 24: 43.5, 32: 45.0)
+#endif
+constexpr int kLeafBatchPlain = RT_LEAF_BATCH_PLAIN;
 
 // Lane-level state machine. A lane's whole traversal state is the ADDRESS of the record it visits next (device_types.h NodeDev,
 // rt_api.cpp device_nodes): every record names both successors — `hit` when its box is passed, `skip` when not — so a node visit is
@@ -975,7 +979,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #ifdef RT_SERVE_BEST
         bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(is_walking()) == 0ull);
 #else
-        const bool do_prims = pm != 0ull && ((int)__popcll(pm) >= kLeafBatch || __ballot(is_walking()) == 0ull);
+        const bool do_prims = pm != 0ull && ((int)__popcll(pm) >= (FEAT == 0u ? kLeafBatchPlain : kLeafBatch) || __ballot(is_walking()) == 0ull);
 #endif
         // Scenes with four or more primitive kinds (book-2 final: spheres, a moving sphere, rects, media): a pass serves ONE
         // kind, the one most lanes wait with; the others stay parked and win a later pass. Every kind's code then runs with
