@@ -423,7 +423,10 @@ DEVI uint32_t find_tile(const RenderDev& rd, uint64_t key, uint32_t scale, uint3
 }
 DEVI WorkItem decode_work(const RenderDev& rd, uint32_t w) {
     uint32_t lt, r;
-    if (rd.row_items != 0u) {
+    if (rd.tiles_all_full != 0u) {
+        lt = fdivu(w, rd.div_item_tile);
+        r = w - lt * (rd.tile_size * rd.tile_size * rd.n_blocks);
+    } else if (rd.row_items != 0u) {
         // one device renders every tile: a row of tiles holds tile_size * width pixels whether its last tile is clipped or not (only the
         // last row can be short), so the tile is two divisions away. The search below costs a path that starts a new item up to five
         // dependent loads (1200 x 800 in 32 x 32 tiles: every row ends in half a tile, the guess is off by up to 13 tiles).
@@ -467,7 +470,8 @@ DEVI uint32_t item_slot(const RenderDev& rd, uint32_t item) {
     const bool full = w == rd.tile_size && h == rd.tile_size;
     const uint32_t p = full ? (((py >> 3) * (rd.tile_size >> 3) + (px >> 3)) << 6) + ((py & 7u) << 3) + (px & 7u) : py * w + px;
     // items before the tile: from the table, or (one device, every tile: decode_work) rows of tiles above + full-width tiles to the left
-    const uint32_t before = rd.row_items != 0u ? ty * rd.row_items + tx * (rd.tile_size * h * rd.n_blocks) : rd.tile_prefix[lt] * rd.n_blocks;
+    const uint32_t before = rd.tiles_all_full != 0u ? lt * (rd.tile_size * rd.tile_size * rd.n_blocks)
+                          : rd.row_items != 0u ? ty * rd.row_items + tx * (rd.tile_size * h * rd.n_blocks) : rd.tile_prefix[lt] * rd.n_blocks;
     return before + blk * (w * h) + p;
 }
 

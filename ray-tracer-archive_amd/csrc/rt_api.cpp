@@ -712,6 +712,8 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
         const uint64_t row_items = (uint64_t)tl.ts * prm->width * rd.n_blocks;
         const bool by_rows = sc == 1u && fits && row_items <= 0xFFFFFFFFull && !(getenv("RT_TILE_SEARCH") && getenv("RT_TILE_SEARCH")[0] == '1');   // (scripts/ only: the search, for A/B)
         rd.row_items = by_rows ? (uint32_t)row_items : 0u;
+        // any shard whose tiles all lie inside the image: the table is a multiplication (the 4096^2 strong-scaling frame at every shard count)
+        rd.tiles_all_full = fits && clipped == 0 && !(getenv("RT_TILE_SEARCH") && getenv("RT_TILE_SEARCH")[0] == '1') ? 1u : 0u;
         rd.div_row_items = rtk::make_fastdiv(by_rows ? (uint32_t)row_items : 1u);
     }
 
