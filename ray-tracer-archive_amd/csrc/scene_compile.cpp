@@ -462,9 +462,7 @@ struct Compiler {
         // wave's next sphere pass like any leaf's), the walk then starts with that hit's t_max, and the tree of the others
         // keeps tight boxes. BVHNode::hit keeps the closest of its members' hits whatever their order (bvh.rs:134-143), so the hit is the
         // same; the test COUNTS are not the reference's (CompileOptions::big_spheres_first = false restores those).
-        // (Not with RT_BVH_SAH: that builder splits such a sphere off near the root by itself — book-1 on the SAH tree 35.6 ms with it in the tree,
-        // 36.7 with it tested first.)
-        if (big_spheres_first && d.bvh_builder != RT_BVH_SAH && out.first_leaf == 0u && n >= 3 && every_ray_enters(id, ctx)) {
+        if (big_spheres_first && out.first_leaf == 0u && n >= 3 && every_ray_enters(id, ctx)) {
             Box3 all = B.box[0];
             for (int c = 1; c < n; ++c) all = surrounding(all, B.box[c]);
             std::vector<char> big((size_t)n, 0); int n_big = 0;
@@ -472,6 +470,12 @@ struct Compiler {
                 const RtHittable* m = H(B.obj[c]); if (!m) return;
                 if (m->kind == RT_HIT_SPHERE && half_area(B.box[c]) >= 0.5 * half_area(all)) { big[(size_t)c] = 1; ++n_big; }
             }
+            // RT_BVH_SAH splits such a sphere off near the root by itself (book-1 on that tree: 35.6 ms with it in the tree, 36.7 with it tested
+            // in the walk's first pass) — but not where it can be tested where the rays are MADE (RenderDev::first_in_shade: one sphere, a scene
+            // without motion or media): there the SAH tree gains as the reference-shaped one does (37.0 -> 32.1 ms)
+            bool still = true;
+            for (uint64_t i = 0; i < d.n_hittables && still; ++i) still = d.hittables[i].kind != RT_HIT_MOVING_SPHERE && d.hittables[i].kind != RT_HIT_CONSTANT_MEDIUM;
+            if (d.bvh_builder == RT_BVH_SAH && !(still && n_big == 1)) n_big = 0;
             if (n_big != 0 && n - n_big >= 2) {
                 Build K; for (int a = 0; a < 3; ++a) K.key[a].reserve((size_t)(n - n_big));
                 const uint32_t first = (uint32_t)out.sphere_meta.size();

@@ -251,7 +251,7 @@ def test_sah_tree_is_a_valid_accelerator(pkg, orc):
         desc = b.desc(b.bvh(ids))
         nodes, spheres, _ = pkg.compile_dump(desc, flags)
         first = [k for w in pkg.compile_info(desc, flags)["first"] for k in range(w & 0xFFFFFF, (w & 0xFFFFFF) + ((w >> 24) & 15))]
-        assert len(first) == (0 if flags or builder == A.RT_BVH_SAH else 1)   # the ground sphere is tested before the walk in the reference-shaped tree, unless the layout is the reference's
+        assert len(first) == (0 if flags else 1)                # the ground sphere is tested before the walk, unless the layout is the reference's
         assert np.all(nodes["skip"] > np.arange(len(nodes)))
         total = 0
         rr = np.random.default_rng(9)
