@@ -92,6 +92,28 @@ def test_bit_exact_invariances(pkg, gpu, book1):
         assert np.array_equal(D.assemble(base, np.stack(parts), world), a)
     f, _ = gpu.render(scene, cam, pkg.make_params(W, H, SPP, seed=6))
     assert not np.array_equal(a, f)
+    # where the ground sphere is tested changes nothing either: where the ray is made (default), in the walk's first pass (a counting render),
+    # as a leaf of the reference's own tree (RT_LAYOUT_LISTS_AS_REFERENCE); nor does the tail's hand-over to the per-path kernel
+    A = pkg._abi
+    k, stc = gpu.render(scene, cam, pkg.make_params(W, H, SPP, seed=5, flags=A.RT_FLAG_COUNTERS))
+    assert np.array_equal(a, k) and stc["prim_tests"][0] > 0
+    ref_tree = gpu.upload(hs.desc, A.RT_LAYOUT_LISTS_AS_REFERENCE)
+    m, stm = gpu.render(ref_tree, cam, pkg.make_params(W, H, SPP, seed=5, flags=A.RT_FLAG_COUNTERS))
+    assert np.array_equal(a, m) and stm["node_tests"] > 1.15 * stc["node_tests"]       # the ground in the tree: every box above it is the scene's size
+    n_, _ = gpu.render(scene, cam, pkg.make_params(W, H, SPP, seed=5, tail_paths=1))
+    assert np.array_equal(a, n_)
+    # an image whose tiles are all full (128 x 96 in 32 x 32 tiles): a shard finds an item's tile by one division, one device by rows; same bits
+    W2, H2 = 128, 96
+    cam2 = hs.camera(W2 / H2)
+    full, _ = gpu.render(scene, cam2, pkg.make_params(W2, H2, 6, seed=9))
+    for world in (2, 5):
+        base = pkg.make_params(W2, H2, 6, seed=9)
+        n = D.shard_floats(base, world)
+        parts = []
+        for r in range(world):
+            buf, _ = gpu.render(scene, cam2, D.shard_params(base, r, world))
+            parts.append(np.concatenate([buf, np.zeros(n - len(buf), np.float32)]))
+        assert np.array_equal(D.assemble(base, np.stack(parts), world), full)
     # work items of 16 samples (the layout of images of 2^32 - 2^28 samples and more; paths are regenerated in flight and carry a
     # running sum): the same samples, summed block-wise, so equal to rounding; bit-stable against the pool size too
     SB = pkg._abi.RT_FLAG_SAMPLE_BLOCKS
