@@ -1427,6 +1427,10 @@ constexpr uint32_t kShadeThreads = RT_SHADE_THREADS;
 #define RT_SHADE_WAVE_ALLOC 0     // tuning builds (with RT_QUEUES >= 32): every wave allocates for itself — measured, no gain
 #endif
 constexpr bool kShadeWaveAlloc = RT_SHADE_WAVE_ALLOC != 0;
+#ifndef RT_SHADE_GROUP_NEW
+#define RT_SHADE_GROUP_NEW 1
+#endif
+constexpr bool kShadeGroupNew = RT_SHADE_GROUP_NEW != 0;
 DEVI uint32_t block_alloc(bool flag, uint32_t* counter, uint32_t* s_scan) {
     const uint32_t wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint64_t m = __ballot(flag);
@@ -1439,6 +1443,23 @@ DEVI uint32_t block_alloc(bool flag, uint32_t* counter, uint32_t* s_scan) {
     const uint32_t base = s_scan[nw];
     __syncthreads();
     return flag ? base + prefix + lane_rank(m) : 0xFFFFFFFFu;
+}
+
+// Two kinds of taker in one allocation (one returning atomic for both): the `a` threads get the first slots, the `b` threads the slots
+// behind them. Returns the thread's slot (0xFFFFFFFF for a thread that is neither).
+DEVI uint32_t block_alloc_two(bool a, bool b, uint32_t* counter, uint32_t* s_scan) {
+    const uint32_t wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint64_t ma = __ballot(a), mb = __ballot(b);
+    if ((threadIdx.x & 63u) == 0u) s_scan[wave] = (uint32_t)__popcll(ma) | ((uint32_t)__popcll(mb) << 16);     // (<= 64 each)
+    __syncthreads();
+    uint32_t prefix = 0, total = 0;
+    for (uint32_t w = 0; w < nw; ++w) { const uint32_t c = s_scan[w]; prefix += (w < wave) ? c : 0u; total += c; }
+    const uint32_t n_a = total & 0xFFFFu, n_b = total >> 16;
+    if (threadIdx.x == 0u && total != 0u) s_scan[nw] = atomicAdd(counter, n_a + n_b);
+    __syncthreads();
+    const uint32_t base = s_scan[nw];
+    __syncthreads();
+    return a ? base + (prefix & 0xFFFFu) + lane_rank(ma) : b ? base + n_a + (prefix >> 16) + lane_rank(mb) : 0xFFFFFFFFu;
 }
 
 // The same allocation, but the workgroup's survivors leave it ORDERED by `key` (< kSortBins; counting sort in LDS): paths of one key get
@@ -1903,6 +1924,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
     PathState s{}; V3 o = v3(0, 0, 0), d = v3(0, 0, 1); float tm = 0.f;
     unsigned long long c_samples = 0, c_light_rect = 0, c_light_sphere = 0;
     Rng g; g.s = 0; g.n = 0u; uint32_t depth = 0u;
+    bool began = false;                // this thread's path has just begun a new work item (a camera ray)
     if (alive) {
         const Float4 ro = in.ray_o[qbase + i], rdv = in.ray_d[qbase + i], s0 = in.s0[qbase + i];
         const uint32_t sd = in.sd[qbase + i]; const uint2 hit = in.hit[qbase + i];
@@ -1932,7 +1954,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
                 // no counter, no atomic, no barrier (round 2 drew items from a per-queue counter: one returning atomic and three barriers
                 // per workgroup) ----
                 const uint32_t next = w + rd.lineage;
-                if (next < rd.total_items) { start_item(rd, next, s, g, o, d, tm); depth = 0u; }
+                if (next < rd.total_items) { start_item(rd, next, s, g, o, d, tm); depth = 0u; began = true; }
                 else alive = false;
             }
         }
@@ -1960,7 +1982,11 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(SceneDev sc, PoolDev in
             uint32_t base = 0u;
             if ((threadIdx.x & 63u) == 0u && m != 0ull) base = atomicAdd(count_out, (uint32_t)__popcll(m));
             dst = first_lane_u32(base) + lane_rank(m);
-        } else dst = block_alloc(alive, count_out, s_scan);
+        } else {
+            // the paths that go on first, the new camera rays behind them: the waves of k_extend that take the latter walk the same boxes
+            // together (book-1 k_extend -1.2 ms), and it costs the scan nothing
+            dst = kShadeGroupNew ? block_alloc_two(alive && !began, alive && began, count_out, s_scan) : block_alloc(alive, count_out, s_scan);
+        }
         SSTAMP(4);
         if (rd.first_in_shade != 0u && alive) tm = first_sphere_hit(rd, o, d, s.from);
         if (alive) store_path(out, qbase + dst, o, d, tm, s, g.n, depth, with_acc);
