@@ -283,7 +283,7 @@ def main():
         "metric": "Msamples/s (pixels x spp / s), book-1 final scene", "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"book-1 final random-spheres scene (scene_seed 1, 484 spheres, reference-shaped BVH), {W}x{H}, {args.spp} spp, "
+        "config": {"workload": f"book-1 final random-spheres scene (scene_seed 1, 485 spheres: the reference's BVH algorithm over 484 of them, the r = 1000 ground sphere tested before the walk), {W}x{H}, {args.spp} spp, "
                                f"depth 50, seed 1; output rgb_sum left in HBM" + (f"; {n_gpus} ranks, 32x32 tiles round-robin" if n_gpus > 1 else ""),
                    "width": W, "height": H, "spp": args.spp, "max_depth": 50, "pool_slots": stats_acc[0]["pool_slots"] if stats_acc else 0,
                    "bvh_in_lds": stats_acc[0]["bvh_in_lds"] if stats_acc else 0, "gather": gather_path,
