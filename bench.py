@@ -52,7 +52,8 @@ def image_size(n_gpus, base_w=1200, base_h=800):
     if n_gpus == 1:
         return base_w, base_h
     s = math.sqrt(n_gpus)
-    return int(round(base_w * s / 8)) * 8, int(round(base_h * s / 8)) * 8
+    # whole 32 x 32 tiles: a shard whose tiles all lie inside the image finds a path's next work item by arithmetic
+    return int(round(base_w * s / 32)) * 32, int(round(base_h * s / 32)) * 32
 
 
 def other_configs(pkg, ctx, A, B, dev, stream):
