@@ -270,7 +270,9 @@ typedef struct RtUploadOptions {
     uint32_t layout_flags;     /* RT_LAYOUT_* */
     uint32_t lds_top_records;  /* RT_LAYOUT_NODES_32B: records of the top of the tree kept in LDS; 0 = default (1024) */
     uint32_t octant_axes;      /* near-first record arrays: 0 = the library picks the axes that matter; else 8 | mask (x = 1, y = 2, z = 4) */
-    uint32_t leaf_collapse;    /* a box node whose subtree is <= n primitives of one kind becomes a leaf; 0/1 = off (default) */
+    uint32_t leaf_collapse;    /* a box node whose subtree is <= n primitives of one kind becomes a leaf; 0/1 = off (default). Measured slower on every
+                                  BASELINE scene (more primitive tests). The one switch that can move a sample: a ray that grazes a sphere within the
+                                  rounding of its box is culled by that box in the other layouts and tested here (a handful of samples in 5e8) */
     float    list_park_cost;   /* cost of a stop at a leaf in primitive tests, for the grouping of culled list members; 0 = default (6) */
 } RtUploadOptions;
 int rt_scene_upload_ex(RtCtx* ctx, const RtSceneDesc* desc, const RtUploadOptions* options /* NULL = defaults */, RtScene** out_scene);
