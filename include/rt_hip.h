@@ -242,7 +242,10 @@ int rt_scene_upload(RtCtx* ctx, const RtSceneDesc* desc, RtScene** out_scene);
 int rt_scene_destroy(RtCtx* ctx, RtScene* scene);
 
 /* ---- how a scene is laid out on the device: per upload, in the ABI (a host with threads cannot set process environment per scene) ----
- * None of these changes a picture: they trade box tests, primitive tests and memory against each other. The defaults are what
+ * None of these changes a picture: they trade box tests, primitive tests and memory against each other. (Exactly: a ray that meets two
+ * primitives at the SAME t — a sphere at its point of contact with the plane it rests on — is given to the one tested later, here as in
+ * the reference, hittable_list.rs:40-47; layouts test in different orders. In the 1 M-sphere scene, where every sphere rests on the
+ * ground rect, 2e-4 of the pixels hold such a sample; in the books' scenes none does.) The defaults are what
  * the library measures fastest; RT_LAYOUT_REFERENCE_COUNTERS is the layout whose RtStats test counts are the reference's own
  * (HittableList::hit probing every member, hittable_list.rs:39-51; BVHNode::hit visiting left then right, bvh.rs:134-143) — the
  * parity tests compare those counts with the CPU oracle's. Environment variables of the same names as in scripts/ still exist

@@ -121,7 +121,7 @@ struct RenderDev {
     // The sphere every walk tests first (SceneDev::walk_start), tested where the ray is MADE — k_generate, k_shade: full waves — instead of
     // in the walk's first primitive pass (a third of a wave's lanes): the ray record's time slot then carries that hit's t (or inf) to k_extend.
     // Only in scenes without motion (the time is used by nothing), with ONE such sphere, and not while counting.
-    uint32_t first_in_shade, first_id; float first_sphere[4];
+    uint32_t first_in_shade, first_id; float first_prim[8];      // centre + radius, or a rect's two records (a0 a1 b0 b1 | k axis)
     uint32_t tiles_all_full;      // every tile of this shard lies inside the image (4096 x 4096 in 32 x 32 tiles, any shard count): tile = item / (ts^2 * n_blocks), no table
     uint32_t row_items;           // unsharded renders: work items of one full-height row of tiles (tile_size * width * n_blocks), 0 = not used. Every
     FastDiv div_row_items;        // such row holds the same number, clipped edge tile or not, so item -> tile is arithmetic (no search in tile_prefix)

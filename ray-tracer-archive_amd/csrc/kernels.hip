@@ -475,8 +475,8 @@ DEVI uint32_t item_slot(const RenderDev& rd, uint32_t item) {
     return before + blk * (w * h) + p;
 }
 
-// RenderDev::first_in_shade: the hit of the ray (o, d), which starts on primitive `from`, with the sphere every walk tests first — the
-// very calls the walk's sphere pass would make for it (kernels.hip LT_SPHERE pass), so the frame does not depend on where it is tested.
+// RenderDev::first_in_shade: the hit of the ray (o, d), which starts on primitive `from`, with the sphere or rect every walk tests first —
+// the very calls the walk's primitive pass would make for it (kernels.hip LT_SPHERE / LT_RECT pass), so the frame does not depend on where it is tested.
 // Returns t, or +inf.
 DEVI float first_sphere_hit(const RenderDev& rd, V3 o, V3 d, uint32_t from);
 
@@ -1494,8 +1494,14 @@ DEVI uint32_t block_alloc_sorted(bool flag, uint32_t key, uint32_t* counter, uin
 }
 
 DEVI float first_sphere_hit(const RenderDev& rd, V3 o, V3 d, uint32_t from) {
-    const V3 c = v3(rd.first_sphere[0], rd.first_sphere[1], rd.first_sphere[2]); const float r = rd.first_sphere[3], a = len2(d);
     float t = kInf, tt;
+    if ((rd.first_id >> 28) == rtd::LT_RECT) {            // (the rect pass's call: kernels.hip LT_RECT)
+        const Float4 r0 = Float4{rd.first_prim[0], rd.first_prim[1], rd.first_prim[2], rd.first_prim[3]}, r1 = Float4{rd.first_prim[4], rd.first_prim[5], 0.f, 0.f};
+        float ha, hb;
+        if (rd.first_id != from && rect_hit(o, d, r0, r1, kTMin, kInf, tt, ha, hb)) t = tt;
+        return t;
+    }
+    const V3 c = v3(rd.first_prim[0], rd.first_prim[1], rd.first_prim[2]); const float r = rd.first_prim[3], a = len2(d);
     const int fast = rd.first_id == from ? 2 : sphere_fast(o, d, a, c, r, kTMin, kInf, tt);
     if (fast == 1) t = tt;
     if (fast == 2) {

@@ -609,10 +609,15 @@ int rti::scene_image_upload(RtCtx* ctx, const SceneImage& im, RtScene** out_scen
     s->features = im.features;
     s->in_lds = im.in_lds; s->lds_bytes = lds_scene_bytes(cs);
     s->bg_mode = cs.background_mode; for (int i = 0; i < 3; ++i) s->bg[i] = cs.background[i];
-    if (cs.first_leaf != 0u && ((cs.first_leaf >> 24) & 15u) == 1u && (cs.first_leaf >> 28) == rtd::LT_SPHERE) {
-        const uint32_t k = cs.first_leaf & rtd::LEAF_MAX_FIRST;
-        s->first_id = (rtd::LT_SPHERE << 28) | k;
-        s->first_sphere[0] = cs.spheres[k].x; s->first_sphere[1] = cs.spheres[k].y; s->first_sphere[2] = cs.spheres[k].z; s->first_sphere[3] = cs.spheres[k].w;
+    if (cs.first_leaf != 0u && ((cs.first_leaf >> 24) & 15u) == 1u) {
+        const uint32_t k = cs.first_leaf & rtd::LEAF_MAX_FIRST, type = cs.first_leaf >> 28;
+        if (type == rtd::LT_SPHERE) {
+            s->first_id = (rtd::LT_SPHERE << 28) | k;
+            s->first_prim[0] = cs.spheres[k].x; s->first_prim[1] = cs.spheres[k].y; s->first_prim[2] = cs.spheres[k].z; s->first_prim[3] = cs.spheres[k].w;
+        } else if (type == rtd::LT_RECT) {
+            s->first_id = (rtd::LT_RECT << 28) | k;
+            std::memcpy(s->first_prim, &cs.rects[2 * k], 32);
+        }
     }
     s->n_nodes = cs.nodes.size();
     s->n_prims = cs.sphere_meta.size() + cs.moving_meta.size() + cs.rect_meta.size() + cs.tri_meta.size() + cs.media.size();
@@ -793,7 +798,7 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
     rd.q_lo = 0u; rd.q_n = rtk::kQueues; rd.q_shift = rtk::kQShift;
     // the ground sphere tested where a ray is made (kernels.h RenderDev::first_in_shade): a scene without motion, one such sphere, no counting
     rd.first_in_shade = scene->first_id != 0u && rtk::can_test_first_in_shade(scene->features) && !counting && !(getenv("RT_FIRST_IN_SHADE") && getenv("RT_FIRST_IN_SHADE")[0] == '0') ? 1u : 0u;
-    rd.first_id = scene->first_id; for (int k = 0; k < 4; ++k) rd.first_sphere[k] = scene->first_sphere[k];
+    rd.first_id = scene->first_id; for (int k = 0; k < 8; ++k) rd.first_prim[k] = scene->first_prim[k];
     HIP_TRY(ctx, rtk::launch_generate(pd[0], rd, n_init, c_count[0], ctx->stream));
     if (timing) { HIP_TRY(ctx, next_event(e1)); spans.push_back({e0, e1, 2}); }
     // The host never waits for an iteration it has just enqueued: the kernels read the pool size from device memory and size-check

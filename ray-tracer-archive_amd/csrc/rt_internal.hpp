@@ -53,7 +53,7 @@ struct RtScene {
         image_bytes, lights, top_nodes, shade_blob, ext_blob, wide, sphere_mat_a, sphere_mat_b;
     rtk::SceneDev dev{};
     uint32_t features = 0; bool in_lds = false;
-    uint32_t first_id = 0; float first_sphere[4] = {0, 0, 0, 0};   // the ONE sphere every walk tests first (hit id, centre + radius), first_id = 0: none or several
+    uint32_t first_id = 0; float first_prim[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the ONE sphere or rect every walk tests first (hit id; centre + radius, or the rect's two records), first_id = 0: none or several
     int bg_mode = 0; float bg[3] = {0, 0, 0};
     uint64_t n_nodes = 0, n_prims = 0, bytes = 0, lds_bytes = 0;
 };

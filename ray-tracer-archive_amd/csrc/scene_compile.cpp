@@ -242,7 +242,7 @@ struct Compiler {
         case RT_HIT_XY_RECT: case RT_HIT_XZ_RECT: case RT_HIT_YZ_RECT: {
             const int kaxis = h.kind == RT_HIT_XY_RECT ? 2 : (h.kind == RT_HIT_XZ_RECT ? 1 : 0);
             const uint32_t idx = add_rect(kaxis, p[0], p[1], p[2], p[3], p[4], meta_for(h, ctx));
-            push_leaf_node(rtd::LT_RECT, idx, 1);
+            if (!to_prologue) push_leaf_node(rtd::LT_RECT, idx, 1);                                        // (else: emit_bvh's first_leaf names it)
             break;
         }
         case RT_HIT_TRIANGLE:
@@ -465,10 +465,13 @@ struct Compiler {
         if (big_spheres_first && out.first_leaf == 0u && n >= 3 && every_ray_enters(id, ctx)) {
             Box3 all = B.box[0];
             for (int c = 1; c < n; ++c) all = surrounding(all, B.box[c]);
-            std::vector<char> big((size_t)n, 0); int n_big = 0;
+            // (spheres or rects — the ground of the 1 M-sphere scene is a 1200 x 1200 rect —, the kind of the first one found: a leaf word names one kind)
+            std::vector<char> big((size_t)n, 0); int n_big = 0; bool rects = false;
+            auto is_rect = [](int k) { return k == RT_HIT_XY_RECT || k == RT_HIT_XZ_RECT || k == RT_HIT_YZ_RECT; };
             for (int c = 0; c < n && n_big < 4; ++c) {
                 const RtHittable* m = H(B.obj[c]); if (!m) return;
-                if (m->kind == RT_HIT_SPHERE && half_area(B.box[c]) >= 0.5 * half_area(all)) { big[(size_t)c] = 1; ++n_big; }
+                const bool sphere = m->kind == RT_HIT_SPHERE, rect = is_rect(m->kind);
+                if ((sphere || rect) && (n_big == 0 || rect == rects) && half_area(B.box[c]) >= 0.5 * half_area(all)) { big[(size_t)c] = 1; rects = rect; ++n_big; }
             }
             // RT_BVH_SAH splits such a sphere off near the root by itself (book-1 on that tree: 35.6 ms with it in the tree, 36.7 with it tested
             // in the walk's first pass) — but not where it can be tested where the rays are MADE (RenderDev::first_in_shade: one sphere, a scene
@@ -478,12 +481,12 @@ struct Compiler {
             if (d.bvh_builder == RT_BVH_SAH && !(still && n_big == 1)) n_big = 0;
             if (n_big != 0 && n - n_big >= 2) {
                 Build K; for (int a = 0; a < 3; ++a) K.key[a].reserve((size_t)(n - n_big));
-                const uint32_t first = (uint32_t)out.sphere_meta.size();
+                const uint32_t first = rects ? (uint32_t)out.rect_meta.size() : (uint32_t)out.sphere_meta.size();
                 for (int c = 0; c < n; ++c) {
                     if (big[(size_t)c]) { to_prologue = true; emit(B.obj[c], ctx, depth + 1); to_prologue = false; continue; }   // (consecutive in the sphere table)
                     K.obj.push_back(B.obj[c]); K.box.push_back(B.box[c]); for (int a = 0; a < 3; ++a) K.key[a].push_back(B.key[a][c]);
                 }
-                out.first_leaf = rtd::make_leaf(rtd::LT_SPHERE, first, (uint32_t)n_big);
+                out.first_leaf = rtd::make_leaf(rects ? rtd::LT_RECT : rtd::LT_SPHERE, first, (uint32_t)n_big);
                 B = std::move(K); n -= n_big;
             }
         }
