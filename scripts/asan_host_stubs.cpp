@@ -4,6 +4,7 @@
 #include "../ray-tracer-archive_amd/csrc/kernels.h"
 namespace rtk {
 const char* launch_note() { return "asan host build: no kernels"; }
+bool can_test_first_in_shade(uint32_t) { return false; }
 hipError_t launch_generate(const PoolDev&, const RenderDev&, uint32_t, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_extend(const LaunchCfg&, const SceneDev&, const PoolDev&, const RenderDev&, const uint32_t*, uint32_t*, uint32_t*, unsigned long long*, bool, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_drain(const LaunchCfg&, const SceneDev&, const PoolDev&, const RenderDev&, uint32_t, const uint32_t*, uint32_t*, uint32_t*, unsigned long long*, bool, hipStream_t) { return hipErrorNotSupported; }
