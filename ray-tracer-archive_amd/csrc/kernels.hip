@@ -224,6 +224,13 @@ DEVI bool sphere_roots(V3 o, V3 d, float a, V3 c, float r, float tmin, float tma
 #ifndef RT_SPHERE_TOL
 #define RT_SPHERE_TOL 1e-5f     // accepted error of a root, in units of the ray parameter
 #endif
+// A sphere of this radius or more goes the f64 way at once, wherever it is tested: the f32 form above could decide it only for rays with
+// |d| of several units (its c/q root needs eps (|oc|^2 + r^2) < tol |q|), and a rule that is the sphere's alone keeps every path that
+// tests it — the walk's sphere pass, the test where a ray is made (first_sphere_hit) — on the same arithmetic.
+#ifndef RT_BIG_SPHERE_RADIUS
+#define RT_BIG_SPHERE_RADIUS 256.f
+#endif
+constexpr float kBigSphere = RT_BIG_SPHERE_RADIUS;
 DEVI int sphere_fast(V3 o, V3 d, float a, V3 c, float r, float tmin, float tmax, float& t) {
     constexpr float kEps = 5.9604645e-8f;                                   // 2^-24
     const V3 oc = o - c;
@@ -1044,7 +1051,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
                     if (COUNT) c_prims[0]++;
                     const uint32_t id = (rtd::LT_SPHERE << 28) | (first + k);
                     float t;
-                    const int r = id == from ? 2 : sphere_fast(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t);
+                    const int r = (id == from || s.w >= kBigSphere) ? 2 : sphere_fast(o, d, a, v3(s.x, s.y, s.z), s.w, kTMin, tmax, t);
                     if (r == 1) { tmax = t; hit_prim = id; }
                     surv |= (r == 2 ? 1u : 0u) << k;
                 }
@@ -1320,7 +1327,7 @@ __global__ void __launch_bounds__(256) k_extend_wide(SceneDev sc, PoolDev pool, 
                     const Float4 sp4 = sc.spheres[idx];
                     id = (rtd::LT_SPHERE << 28) | idx;
                     float tt;
-                    const int r = id == from ? 2 : sphere_fast(o, d, a, v3(sp4.x, sp4.y, sp4.z), sp4.w, kTMin, tmax, tt);
+                    const int r = (id == from || sp4.w >= kBigSphere) ? 2 : sphere_fast(o, d, a, v3(sp4.x, sp4.y, sp4.z), sp4.w, kTMin, tmax, tt);
                     bool h = r == 1;
                     if (r == 2) h = (id == from) ? sphere_hit_from_surface(o, d, a, v3(sp4.x, sp4.y, sp4.z), sp4.w, kTMin, tmax, tt)
                                                  : sphere_roots(o, d, a, v3(sp4.x, sp4.y, sp4.z), sp4.w, kTMin, tmax, tt);
@@ -1502,7 +1509,7 @@ DEVI float first_sphere_hit(const RenderDev& rd, V3 o, V3 d, uint32_t from) {
         return t;
     }
     const V3 c = v3(rd.first_prim[0], rd.first_prim[1], rd.first_prim[2]); const float r = rd.first_prim[3], a = len2(d);
-    const int fast = rd.first_id == from ? 2 : sphere_fast(o, d, a, c, r, kTMin, kInf, tt);
+    const int fast = (rd.first_id == from || r >= kBigSphere) ? 2 : sphere_fast(o, d, a, c, r, kTMin, kInf, tt);     // (uniform: a scalar branch)
     if (fast == 1) t = tt;
     if (fast == 2) {
         const bool h = rd.first_id == from ? sphere_hit_from_surface(o, d, a, c, r, kTMin, kInf, tt) : sphere_roots(o, d, a, c, r, kTMin, kInf, tt);
