@@ -346,3 +346,45 @@ def test_random_graphs_render_the_same_under_every_layout(pkg, gpu, seed):
     img_d, sd = gpu.render(gpu.upload(desc), cam, prm)          # what the uploader picks by itself
     assert np.array_equal(img_d, ref) and sd["segments"] == sr["segments"], seed
     assert sum(st["prim_tests"][:5]) < sum(sr["prim_tests"][:5])
+
+
+@pytest.mark.parametrize("ground", ["rect", "sphere", "two_spheres"])
+def test_scene_sized_primitive_tested_first(pkg, orc, gpu, ground):
+    """A rect or sphere of the root BVH as large as the scene is tested before the walk and kept out of the tree (where nothing moves and it
+    is the only one: where the ray is made). Same frame, bit for bit, as with it IN the tree (RT_LAYOUT_LISTS_AS_REFERENCE), as a counting
+    render (tested in the walk's first pass), and on the SAH tree — the spheres float above the ground, so no two hits tie — and the oracle's."""
+    A = pkg._abi
+    frames, visits = [], []
+    for builder in (A.RT_BVH_REFERENCE, A.RT_BVH_SAH):
+        b = pkg.SceneBuilder(background=(0.7, 0.8, 1.0), bvh_seed=3, bvh_builder=builder)
+        grey, glass, metal = b.lambertian((0.5, 0.5, 0.5)), b.dielectric(1.5), b.metal((0.8, 0.6, 0.2), 0.1)
+        r = np.random.default_rng(4)
+        ids = []
+        for k in range(80):
+            rad = r.uniform(0.2, 0.6)
+            ids.append(b.sphere((r.uniform(-8, 8), rad + 0.05 + r.uniform(0, 0.5), r.uniform(-8, 8)), rad, [b.lambertian(tuple(r.uniform(0.1, 0.9, 3))), glass, metal][k % 3]))
+        if ground == "rect":
+            ids.append(b.xz_rect(-60, 60, -60, 60, 0.0, grey))
+        else:
+            ids.append(b.sphere((0, -1000, 0), 1000, grey))
+            if ground == "two_spheres":
+                ids.append(b.sphere((0, 0, -1030), 1000, metal))          # a second scene-sized sphere: both go first, tested in the walk's first pass
+        desc = b.desc(b.bvh(ids))
+        info = pkg.compile_info(desc)
+        assert len(info["first"]) == (1 if not (builder == A.RT_BVH_SAH and ground == "two_spheres") else 0)
+        if info["first"]:
+            assert (info["first"][0] >> 28) == (3 if ground == "rect" else 1) and ((info["first"][0] >> 24) & 15) == (2 if ground == "two_spheres" else 1)
+        cam = pkg.camera_new((10, 3, 12), (0, 0.5, 0), (0, 1, 0), 35, 4 / 3, 0.05, 15.0, 0, 0)
+        prm = pkg.make_params(128, 96, 8, seed=2)
+        img, _ = gpu.render(gpu.upload(desc), cam, prm)
+        cnt, st = gpu.render(gpu.upload(desc), cam, pkg.make_params(128, 96, 8, seed=2, flags=A.RT_FLAG_COUNTERS))
+        ref, st_ref = gpu.render(gpu.upload(desc, A.RT_LAYOUT_LISTS_AS_REFERENCE), cam, pkg.make_params(128, 96, 8, seed=2, flags=A.RT_FLAG_COUNTERS))
+        assert np.array_equal(img, cnt) and np.array_equal(img, ref)
+        if info["first"]:
+            assert st["node_tests"] < st_ref["node_tests"]
+        frames.append(img); visits.append(st["node_tests"])
+        if builder == A.RT_BVH_REFERENCE:
+            o, _ = orc.render(desc, cam, prm, precision=64, n_threads=8)
+            d = np.abs(img.astype(np.float64) - o) / 8
+            assert d.mean() < 4e-5 and float((d.max(axis=2) > 2e-3).mean()) < 0.01
+    assert np.array_equal(frames[0], frames[1])
