@@ -156,14 +156,19 @@ def main():
     if args.gpus != n_gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; on a box with FEWER GPUs than ranks (the one-GPU rehearsal of the N > 1 path) ranks share devices: RCCL then refuses
+    # the communicator and the staged gather below takes over, which is the point of the rehearsal
+    device_index = local_rank % max(1, torch.cuda.device_count())
+    if device_index != local_rank and rank == 0:
+        print(f"note: {world} ranks on {torch.cuda.device_count()} GPU(s): ranks share devices (rehearsal; not a scaling measurement)", file=sys.stderr)
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     # a real (non-null) torch stream, made current: the library launches on it, and HIP events recorded by the library see
     # every kernel of a step
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    ctx = pkg.Context(local_rank, stream.cuda_stream)
+    ctx = pkg.Context(device_index, stream.cuda_stream)
     gather_path = "single GPU"
     staged_why = None
     if n_gpus > 1:
@@ -288,6 +293,7 @@ def main():
                                f"depth 50, seed 1; output rgb_sum left in HBM" + (f"; {n_gpus} ranks, 32x32 tiles round-robin" if n_gpus > 1 else ""),
                    "width": W, "height": H, "spp": args.spp, "max_depth": 50, "pool_slots": stats_acc[0]["pool_slots"] if stats_acc else 0,
                    "bvh_in_lds": stats_acc[0]["bvh_in_lds"] if stats_acc else 0, "gather": gather_path,
+                   **({"ranks_share_devices": True} if device_index != int(os.environ.get("LOCAL_RANK", "0")) else {}),
                    "timing": "mean over the timed steps, frame left in HBM (SURVEY 8(d) asks for the host-resident median: +1 copy of 11.5 MB, < 1 ms; DESIGN.md section 5)"},
         "kernel_ms_per_step": {"k_extend": round(ext_ms / args.steps, 3), "k_shade": round(shade_ms / args.steps, 3), "generate+resolve": round(other_ms / args.steps, 3),
                                "gather+untile": round(gather_ms / args.steps, 3), "launches_per_step": launches // max(1, args.steps)},
