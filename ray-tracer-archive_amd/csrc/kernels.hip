@@ -1427,8 +1427,8 @@ DEVI void store_path(const PoolDev& p, uint32_t i, V3 o, V3 d, float tm, const P
 // serialise at the L2, so per-wave atomics would bound the kernel). wave64 ballot + prefix inside a
 // wave, a tiny LDS scan across waves.
 #ifndef RT_SHADE_THREADS
-#define RT_SHADE_THREADS 512
-#endif
+#define RT_SHADE_THREADS 256      // four waves share a workgroup's two barriers and its one atomic (512: book-1 k_shade 32.9 -> 31.8 ms, book-2 final 29.9 -> 28.4,
+#endif                            // Cornell 29.8 -> 29.1; 1024: 48 ms). Round 2 found no difference: its k_shade still drew work items from a counter per workgroup
 constexpr uint32_t kShadeThreads = RT_SHADE_THREADS;
 #ifndef RT_SHADE_WAVE_ALLOC
 #define RT_SHADE_WAVE_ALLOC 0     // tuning builds (with RT_QUEUES >= 32): every wave allocates for itself — measured, no gain
