@@ -709,6 +709,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
 #ifdef RT_STAMPS
     unsigned long long st_refill = 0, st_node = 0, st_prim = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
     unsigned long long st_pass[6] = {0, 0, 0, 0, 0, 0}, st_lanes[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_steps = 0, st_walking = 0;       // node steps of this wave, and the lanes that were on a tree record when each began
 #define STAMP(x) x = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(x)
@@ -889,6 +890,9 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         STAMP(st_b);
 #endif
         // ---- node pass: kSteps visits, every lane, no exec-mask traffic: two 16-byte reads, 5 packed + 8 plain VALU, one select ----
+#ifdef RT_STAMPS
+        { const uint64_t wm = __ballot(is_walking()); if (lane == 0u) { st_steps += (unsigned long long)kSteps; st_walking += (unsigned long long)kSteps * (unsigned long long)__popcll(wm); } }
+#endif
         if constexpr (!C16) {
 #pragma unroll
         for (int step = 0; step < kSteps; ++step) {
@@ -1175,6 +1179,7 @@ __global__ void __launch_bounds__(TPB) k_extend(SceneDev sc, PoolDev pool, const
         if (!COUNT) {
             atomicAdd(&counters[CTR_NODE_TESTS], st_pass[5]);
             for (int k = 0; k < 5; ++k) atomicAdd(&counters[CTR_PRIM_TESTS + k], (st_pass[k] << 40) | st_lanes[k]);
+            atomicAdd(&counters[CTR_SAMPLES], st_steps); atomicAdd(&counters[CTR_PRIM_TESTS + 5], st_walking);
         }
     }
 #endif

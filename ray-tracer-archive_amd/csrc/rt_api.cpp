@@ -935,6 +935,9 @@ static int render_impl(RtCtx* ctx, const RtScene* scene, const RtCamera* cam, co
             for (int k = 0; k < RT_N_PRIM_TYPES; ++k) stats->prim_tests[k] = ctx->h_counters[rtk::CTR_PRIM_TESTS + k];
         }
         for (int k = 0; k < 5; ++k) stats->debug[k] = ctx->h_counters[rtk::CTR_DEBUG + k];
+#ifdef RT_STAMPS
+        stats->debug[5] = ctx->h_counters[rtk::CTR_SAMPLES];       // node steps of all waves (scripts/gpu_stamps.py)
+#endif
         stats->debug[6] = extend_geometry[0]; stats->debug[7] = extend_geometry[1];   // k_extend: threads per workgroup, resident workgroups per CU
         stats->iterations = (uint32_t)ctx->h_counters[rtk::CTR_ITERATIONS]; stats->extend_launches = launched; stats->shade_launches = launched; stats->pool_slots = P;
         stats->n_devices = 1u; stats->lds_top_nodes = scene->dev.n_top; stats->drain_paths = drained;

@@ -26,6 +26,8 @@ d = st['debug']
 tot = d[3]
 print(which, "waves", d[4], "refill %.1f%% node %.1f%% prim %.1f%% other %.1f%%" % (100*d[0]/tot, 100*d[1]/tot, 100*d[2]/tot, 100*(tot-d[0]-d[1]-d[2])/tot), "cycles/wave %.0f" % (tot/d[4]),
       "extend_ms %.1f" % st['extend_ms'], "shade_ms %.1f" % st['shade_ms'], "iters", st['iterations'], "geom", st['debug'][6:8])
+if d[5]:
+    print("  node steps per wave %.0f; lanes on a tree record when a step begins: %.1f of 64 (the rest are parked at a leaf, idle or done)" % (d[5] / d[4], st["prim_tests"][5] / d[5]))
 if not (prm.flags & 1):
     names = ["sphere", "moving", "rect", "tri", "medium"]
     print("  prim passes/wave %.1f;" % (st["node_tests"] / d[4]), " ".join("%s: %.1f passes/wave, %.1f lanes/pass;" % (names[k], (v >> 40) / d[4], (v & ((1 << 40) - 1)) / max(1, v >> 40)) for k, v in enumerate(st["prim_tests"][:5]) if v), "segments/wave %.0f" % (st["segments"] / d[4]))
